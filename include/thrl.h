@@ -1,0 +1,182 @@
+/*
+ * thrl.h -- C ABI of libthrl_hip.so: the MI355X (gfx950) implementation of the
+ * iterated-pricing-game hot path of HakimNessah/th_rl.
+ *
+ * The reference has NO FFI / plugin layer: its boundary is the
+ * Python duck-typed protocol that th_rl/trainer.py:46-70 drives.  Each entry
+ * point below therefore cites the reference *Python* code it replaces.  All
+ * pointers marked "device" are device (HBM) pointers owned by the caller
+ * (e.g. torch tensors); the library allocates nothing persistent, never
+ * throws, never exits; every function returns 0 on success or a negative
+ * thrl_err, and thrl_last_error() gives a thread-local message.  Work is
+ * enqueued on the caller's HIP stream (passed as void*, 0 = default stream)
+ * and is asynchronous; the caller synchronises.
+ *
+ * Plain C: no torch / HIP types in any signature.
+ */
+#ifndef THRL_H
+#define THRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THRL_ABI_VERSION 1
+#define THRL_MAXA 8          /* max agents per game (reference configs use 2) */
+#define THRL_MAX_EPISODES_PER_LAUNCH 32
+
+typedef enum {
+    THRL_OK = 0,
+    THRL_ERR_BAD_CONFIG = -1,   /* shape / range error in thrl_cfg              */
+    THRL_ERR_NULL = -2,         /* a required pointer is NULL                   */
+    THRL_ERR_UNSUPPORTED = -3,  /* requested kernel cannot run this config      */
+    THRL_ERR_HIP = -4,          /* HIP runtime error (message has the string)   */
+    THRL_ERR_WORKSPACE = -5     /* workspace / replay memory too small          */
+} thrl_err;
+
+typedef enum {
+    THRL_KERNEL_AUTO = 0,       /* fused wave kernel when eligible, else generic */
+    THRL_KERNEL_GENERIC = 1,    /* one thread per game, tables in HBM, f32/f64  */
+    THRL_KERNEL_WAVE = 2        /* one wavefront per game, tables in LDS, f32   */
+} thrl_kernel;
+
+/*
+ * Game description.  One thrl_cfg == the JSON config blocks that
+ * trainer.create_game() splats into the constructors (trainer.py:13-26):
+ *   per agent  : QTable.__init__ kwargs           (agents.py:13-28)
+ *   environment: NoisyPriceState.__init__ kwargs  (environments.py:5)
+ */
+typedef struct {
+    int32_t n_games;                 /* G: games stepped in lockstep on this device      */
+    int32_t n_agents;                /* N = environment.nplayers = len(agents)           */
+    int32_t max_steps;               /* T = environment.max_steps                        */
+    int32_t q_dtype;                 /* 0 = float32 tables, 1 = float64 tables           */
+    double  env_a, env_b;            /* demand intercept / slope (environments.py:5)     */
+    double  noise_prob;              /* environments.py:28                               */
+    int32_t n_states[THRL_MAXA];     /* QTable `states`  (table has states+1 rows)       */
+    int32_t n_actions[THRL_MAXA];    /* QTable `actions`                                 */
+    int32_t min_memory[THRL_MAXA];   /* agents.py:26,60                                  */
+    int32_t capacity[THRL_MAXA];     /* ReplayBuffer deque maxlen (buffers.py:12)        */
+    double  max_state[THRL_MAXA];    /* agents.py:21,48                                  */
+    double  gamma[THRL_MAXA], alpha[THRL_MAXA];
+    double  eps_end[THRL_MAXA], eps_step[THRL_MAXA];
+    double  act_lo[THRL_MAXA], act_hi[THRL_MAXA];   /* action_range                      */
+} thrl_cfg;
+
+/*
+ * HBM layout (all game-major so one game's data is one contiguous slab):
+ *   q        [G][stride]  stride = sum_i (n_states[i]+1)*n_actions[i]; agent i's
+ *                         block starts at off_i = sum_{j<i} rows_j*A_j and is the
+ *                         reference's `QTable.table` (agents.py:29) row-major.
+ *   counter  [G][stride]  int32, `QTable.counter` (agents.py:45,76); may be NULL.
+ *   state    [G]          float64 env state = last price (environments.py:36).
+ *   replay_mem            opaque, thrl_replay_mem_bytes(); the ReplayBuffer
+ *                         contents that survive between episodes (buffers.py).
+ */
+typedef struct {
+    void*    q;                      /* device, f32 or f64 per cfg.q_dtype               */
+    int32_t* counter;                /* device or NULL                                   */
+    double*  state;                  /* device                                           */
+    void*    replay_mem;             /* device, generic kernel only (may be NULL for WAVE)*/
+    size_t   replay_mem_bytes;
+    double*  reward_log;             /* device [n_episodes][N]: mean over the G games of
+                                        rewards_log[e,:] (trainer.py:65); or NULL        */
+    double*  action_log;             /* device [n_episodes][N] (trainer.py:66); or NULL  */
+    double*  game_reward_log;        /* device [n_episodes][N][G] per-game rows; or NULL */
+    double*  game_action_log;        /* device [n_episodes][N][G]; or NULL               */
+    /* parity mode: the reference's recorded random draws, or NULL for Philox       */
+    const double* inj_u;             /* device [n_episodes][T][N][G] random.uniform(0,1) (agents.py:81) */
+    const int8_t* inj_choice;        /* device [n_episodes][T][N][G] random.choice idx   (agents.py:82) */
+    const double* inj_noise_u;       /* device [n_episodes][T][G]    (environments.py:28); NULL if noise_prob<=0 */
+    const double* inj_noise_a;       /* device [n_episodes][T][G]    (environments.py:29) */
+    void*    workspace;              /* device scratch, thrl_workspace_bytes()           */
+    size_t   workspace_bytes;
+} thrl_buffers;
+
+/* Host-side run state that is identical for every game (so it never lives in HBM). */
+typedef struct {
+    uint64_t seed;                   /* Philox key                                       */
+    uint64_t game_offset;            /* global id of local game 0 (sharding-invariant RNG)*/
+    uint64_t first_episode;          /* global episode index of the first episode        */
+    int32_t  n_episodes;             /* episodes to run in this call                     */
+    int32_t  kernel;                 /* thrl_kernel                                      */
+    double   eps[THRL_MAXA];         /* in/out: QTable.epsilon (agents.py:35,78)         */
+    int32_t  mem_count[THRL_MAXA];   /* in/out: appends since the last memory.empty();
+                                        len(agent.memory) == min(mem_count, capacity)
+                                        (buffers.py:12-19,40); kept in [0, 2*capacity)   */
+    int32_t  kernel_used;            /* out: thrl_kernel actually launched               */
+} thrl_run;
+
+int         thrl_version(void);
+const char* thrl_last_error(void);
+
+/* elements per game in q / counter (sum_i rows_i*A_i); 0 on bad config */
+size_t thrl_table_stride(const thrl_cfg* cfg);
+/* element offset of agent i's table inside one game's slab */
+size_t thrl_table_offset(const thrl_cfg* cfg, int agent);
+size_t thrl_replay_mem_bytes(const thrl_cfg* cfg);
+size_t thrl_workspace_bytes(const thrl_cfg* cfg);
+/* which kernel THRL_KERNEL_AUTO would pick for this config (thrl_kernel) */
+int    thrl_select_kernel(const thrl_cfg* cfg, int injected);
+
+/*
+ * Replaces QTable.__init__ table/counter init (agents.py:29,45) and
+ * NoisyPriceState.reset() (environments.py:50-53, called once at trainer.py:45)
+ * for all G games: q = 12.5/(1-gamma_i) + N(0,1), counter = 0, state ~ U(0,a),
+ * from Philox4x32-10 keyed by (seed, global game id).
+ */
+int thrl_qtable_init(const thrl_cfg* cfg, void* q, int32_t* counter, double* state,
+                     uint64_t seed, uint64_t game_offset, void* stream);
+
+/*
+ * THE hot path: replaces the body of trainer.train_one's loop (trainer.py:46-70)
+ * for `run->n_episodes` episodes of all G games: per step QTable.sample_action
+ * (agents.py:80-89), QTable.scale (:51-57), NoisyPriceState.step
+ * (environments.py:25-39), ReplayBuffer.append (buffers.py:18-19), the log
+ * accumulation (trainer.py:65-66); per episode QTable.train_net
+ * (agents.py:59-78) = ReplayBuffer.replay/empty + snapshot-TD + epsilon decay.
+ */
+int thrl_qtable_episodes(const thrl_cfg* cfg, const thrl_buffers* bufs, thrl_run* run,
+                         void* stream);
+
+/*
+ * Greedy evaluation rollout, replaces utils.play_game (utils.py:27-47):
+ * env.reset() then `iters` episodes of get_action (agents.py:91-92) / scale /
+ * env.step with no learning.  state0 [iters][G] are the reset() draws
+ * (device, or NULL to draw from Philox); outputs are per-game episode means
+ * mean_reward/mean_action [iters][N][G] (device).
+ */
+int thrl_play_greedy(const thrl_cfg* cfg, const void* q, const double* state0,
+                     int32_t iters, uint64_t seed, uint64_t game_offset,
+                     double* mean_reward, double* mean_action, void* stream);
+
+/*
+ * Unfused, batched-over-games operator forms of the reference methods (same
+ * argument meaning, one call = one reference call applied to G games).  They
+ * exist so a caller that drives the step loop itself (the duck-typed protocol)
+ * still runs on the device.
+ */
+/* QTable.sample_action / get_action for agent `agent` (agents.py:80-92):
+ * u/choice device [G] (u==NULL => greedy get_action); price device [G];
+ * encode32 != 0 applies the trainer's float32 cast first (trainer.py:53). */
+int thrl_op_sample_action(const thrl_cfg* cfg, int agent, const void* q, const double* price,
+                          double eps, const double* u, const int8_t* choice, int encode32,
+                          int32_t* action_out, void* stream);
+/* NoisyPriceState.step for G games (environments.py:25-39): actions device [N][G]
+ * int32 indices (scaled inside, agents.py:51-57); noise_u/noise_a device [G] or NULL. */
+int thrl_op_env_step(const thrl_cfg* cfg, const int32_t* actions, const double* noise_u,
+                     const double* noise_a, double* price_out, double* reward_out /*[N][G]*/,
+                     double* scaled_out /*[N][G] or NULL*/, void* stream);
+/* QTable.train_net's table update for agent `agent` on n transitions per game
+ * (agents.py:61-76): price/next_price [n][G] f64, action [n][G] int32, reward [n][G] f64. */
+int thrl_op_td_update(const thrl_cfg* cfg, int agent, void* q, int32_t* counter, int32_t n,
+                      const double* price, const int32_t* action, const double* reward,
+                      const double* next_price, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THRL_H */
