@@ -165,16 +165,23 @@ int thrl_play_greedy(const thrl_cfg* cfg, const void* q, const double* state0,
 int thrl_op_sample_action(const thrl_cfg* cfg, int agent, const void* q, const double* price,
                           double eps, const double* u, const int8_t* choice, int encode32,
                           int32_t* action_out, void* stream);
-/* NoisyPriceState.step for G games (environments.py:25-39): actions device [N][G]
- * int32 indices (scaled inside, agents.py:51-57); noise_u/noise_a device [G] or NULL. */
-int thrl_op_env_step(const thrl_cfg* cfg, const int32_t* actions, const double* noise_u,
-                     const double* noise_a, double* price_out, double* reward_out /*[N][G]*/,
-                     double* scaled_out /*[N][G] or NULL*/, void* stream);
+/* QTable.encode for agent `agent` (agents.py:47-49): price [G] f64 -> row index [G] int32;
+ * as_float32 != 0 evaluates it on the float32-cast state as sample_action does (trainer.py:53). */
+int thrl_op_encode(const thrl_cfg* cfg, int agent, const double* price, int as_float32,
+                   int32_t* row_out, void* stream);
+/* QTable.scale for agent `agent` (agents.py:51-57): action index [G] int32 -> scaled [G] f64 */
+int thrl_op_scale(const thrl_cfg* cfg, int agent, const int32_t* action, double* scaled_out, void* stream);
+/* NoisyPriceState.step for G games (environments.py:25-39): scaled device [N][G] f64 = the
+ * `actions` argument of the reference (already scaled); noise_u/noise_a device [G] or NULL
+ * (the two numpy.random.uniform draws of :28-29); outputs price [G], reward [N][G]. */
+int thrl_op_env_step(const thrl_cfg* cfg, const double* scaled, const double* noise_u,
+                     const double* noise_a, double* price_out, double* reward_out, void* stream);
 /* QTable.train_net's table update for agent `agent` on n transitions per game
- * (agents.py:61-76): price/next_price [n][G] f64, action [n][G] int32, reward [n][G] f64. */
+ * (agents.py:61-76): price/next_price [n][G] f64, action [n][G] int32, reward [n][G] f64;
+ * scratch: device [n][G] f64 (holds the old_value snapshot of agents.py:67). */
 int thrl_op_td_update(const thrl_cfg* cfg, int agent, void* q, int32_t* counter, int32_t n,
                       const double* price, const int32_t* action, const double* reward,
-                      const double* next_price, void* stream);
+                      const double* next_price, double* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle and the
+reference-generated golden fixtures.  Integer/index results and float64 tables
+are compared bit for bit; float32 tables are compared bit for bit against the
+oracle's float32 mode (same op order), and against the float64 reference within
+rtol 1e-5 where stated."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CFG_AGENT = dict(name="QTable", gamma=0.95, actions=21, states=100, alpha=0.1, eps_end=0.001,
+                 epsilon=0.5, eps_step=0.9995, action_range=[0.2, 0.4])
+CFG_ENV = dict(name="NoisyPriceState", noise_prob=0, a=10, b=1, nplayers=2, max_steps=100)
+CFG = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV)}
+
+
+def _batch(config, G, dtype="float32", kernel="auto", seed=0, game_offset=0):
+    from th_rl_amd.batched import GameBatch
+    return GameBatch(config, n_games=G, dtype=dtype, kernel=kernel, seed=seed, game_offset=game_offset)
+
+
+def _oracle_run(config, G, q_dtype, q, state, E, seed=0, game_offset=0, first_episode=0, eps=None, mem=None):
+    cfg, eps0 = O.cfg_from_config(config, n_games=G, q_dtype=q_dtype)
+    eps = eps0 if eps is None else eps
+    mem = O.Memory(cfg) if mem is None else mem
+    q = q.copy(); state = state.copy()
+    counter = np.zeros(q.shape, np.int32)
+    out = O.episodes(cfg, q, counter, state, eps, mem, E, seed=seed, game_offset=game_offset,
+                     first_episode=first_episode)
+    return q, counter, state, eps, mem, out
+
+
+def _traj_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "g4_*.npz")) + glob.glob(os.path.join(GOLDEN, "g5_*.npz")))
+
+
+@pytest.mark.parametrize("path", _traj_files(), ids=os.path.basename)
+def test_generic_f64_injected_matches_reference_golden(path):
+    """The reference's recorded draws in => the reference's tables/counters/logs out,
+    bit for bit (float64 generic kernel)."""
+    d = np.load(path)
+    config = json.loads(str(d["config_json"]))
+    E, T, N = d["u"].shape
+    gb = _batch(config, 1, dtype="float64", kernel="generic")
+    gb.set_tables(d["init_tables"][None, :], [float(d["state0"])])
+    inj = dict(u=d["u"][:, :, :, None], choice=d["choice"][:, :, :, None])
+    if gb.cfg.noise_prob > 0:
+        inj.update(noise_u=d["noise_u"][:, :, None], noise_a=np.nan_to_num(d["noise_a"][:, :, None]))
+    out = gb.run(E, inj=inj, per_game_logs=True)
+    assert out["kernel"] == "generic"
+    assert np.array_equal(gb.tables_numpy()[0], d["final_tables"])
+    assert np.array_equal(gb.counters_numpy()[0].astype(np.float64), d["final_counters"])
+    assert np.array_equal(out["game_reward_log"][:, :, 0], d["rewards_log"])
+    assert np.array_equal(out["game_action_log"][:, :, 0], d["actions_log"])
+    assert np.array_equal(np.array(gb.eps[:N]), d["eps"][-1])
+    assert gb.states_numpy()[0] == d["states"][-1, -1]
+    np.testing.assert_allclose(out["reward_log"], d["rewards_log"], rtol=1e-14)
+
+
+def test_generic_f64_injected_four_games_at_once():
+    """Four different reference runs stepped in lockstep as one batch (G=4)."""
+    ds = [np.load(os.path.join(GOLDEN, "g4_cfg_seed%d_e12.npz" % s)) for s in range(4)]
+    config = json.loads(str(ds[0]["config_json"]))
+    gb = _batch(config, 4, dtype="float64", kernel="generic")
+    gb.set_tables(np.stack([d["init_tables"] for d in ds]), [float(d["state0"]) for d in ds])
+    inj = dict(u=np.stack([d["u"] for d in ds], axis=-1), choice=np.stack([d["choice"] for d in ds], axis=-1))
+    out = gb.run(12, inj=inj, per_game_logs=True)
+    for g, d in enumerate(ds):
+        assert np.array_equal(gb.tables_numpy()[g], d["final_tables"])
+        assert np.array_equal(gb.counters_numpy()[g].astype(np.float64), d["final_counters"])
+        assert np.array_equal(out["game_reward_log"][:, :, g], d["rewards_log"])
+    np.testing.assert_allclose(out["reward_log"], np.mean([d["rewards_log"] for d in ds], axis=0), rtol=1e-13)
+
+
+def test_generic_f32_injected_tracks_reference_within_tolerance():
+    """float32 tables vs the float64 reference: same actions for the first 5
+    episodes, Q-values within rtol 1e-5 (the tolerance north_star allows)."""
+    d = np.load(os.path.join(GOLDEN, "g4_cfg_seed0_e12.npz"))
+    config = json.loads(str(d["config_json"]))
+    E = 5
+    gb = _batch(config, 1, dtype="float32", kernel="generic")
+    gb.set_tables(d["init_tables"][None, :], [float(d["state0"])])
+    out = gb.run(E, inj=dict(u=d["u"][:E, :, :, None], choice=d["choice"][:E, :, :, None]), per_game_logs=True)
+    assert np.array_equal(out["game_reward_log"][:, :, 0], d["rewards_log"][:E])   # same trajectory
+    # float64 reference tables after 5 episodes come from the oracle (pinned to the reference)
+    cfg, eps = O.cfg_from_config(config, 1, 1)
+    q = d["init_tables"][None, :].copy(); c = np.zeros(q.shape, np.int32); s = np.array([float(d["state0"])])
+    O.episodes(cfg, q, c, s, eps, O.Memory(cfg), E, inj_u=np.ascontiguousarray(d["u"][:E, :, :, None]),
+               inj_choice=np.ascontiguousarray(d["choice"][:E, :, :, None]))
+    np.testing.assert_allclose(gb.tables_numpy()[0].astype(np.float64), q[0], rtol=1e-5, atol=0)
+    assert np.array_equal(gb.counters_numpy()[0], c[0])
+
+
+def test_init_matches_oracle():
+    gb = _batch(CFG, 50, dtype="float64", seed=11, game_offset=7).init_tables()
+    cfg, _ = O.cfg_from_config(CFG, 50, 1)
+    q, c, s = O.init(cfg, seed=11, game_offset=7)
+    assert np.array_equal(gb.states_numpy(), s)                   # exact integer->double arithmetic
+    np.testing.assert_allclose(gb.tables_numpy(), q, rtol=0, atol=1e-11)   # libm log/sin/cos differ in ulps
+    assert not gb.counters_numpy().any()
+    tq = gb.tables_numpy()
+    assert abs(tq.mean() - 250.0) < 0.02 and abs(tq.std() - 1.0) < 0.02
+
+
+@pytest.mark.parametrize("kernel,G,E", [("generic", 70, 5), ("wave", 70, 5), ("wave", 333, 20)])
+def test_f32_philox_bit_exact_vs_oracle(kernel, G, E):
+    """Philox draws, float32 tables: tables, counters, env state bit-identical to
+    the oracle's float32 mode; mean logs to 1e-12 (summation order over games)."""
+    gb = _batch(CFG, G, dtype="float32", kernel=kernel, seed=5).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    assert out["kernel"] == kernel
+    q, c, s, eps, mem, oo = _oracle_run(CFG, G, 0, q0, s0, E, seed=5)
+    assert np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    assert np.array_equal(gb.tables_numpy(), q)
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12)
+    np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12)
+    assert np.array_equal(np.array(gb.eps[:2]), eps[:2])
+
+
+def test_wave_equals_generic_and_split_calls():
+    """wave kernel == generic kernel bit for bit, and 7+9 episodes in two calls ==
+    16 in one (tables stay resident in LDS only inside a launch)."""
+    G = 257
+    a = _batch(CFG, G, kernel="wave", seed=9).init_tables()
+    b = _batch(CFG, G, kernel="generic", seed=9).init_tables()
+    c = _batch(CFG, G, kernel="wave", seed=9).init_tables()
+    ra = a.run(16); rb = b.run(16); c.run(7); c.run(9)
+    assert ra["kernel"] == "wave" and rb["kernel"] == "generic"
+    for x in (b, c):
+        assert np.array_equal(a.tables_numpy(), x.tables_numpy())
+        assert np.array_equal(a.counters_numpy(), x.counters_numpy())
+        assert np.array_equal(a.states_numpy(), x.states_numpy())
+    np.testing.assert_allclose(ra["reward_log"], rb["reward_log"], rtol=1e-12)
+
+
+def test_sharding_invariance():
+    """game_offset makes results independent of how games are split over GPUs."""
+    full = _batch(CFG, 96, kernel="wave", seed=2).init_tables(); full.run(4)
+    lo = _batch(CFG, 40, kernel="wave", seed=2, game_offset=0).init_tables(); lo.run(4)
+    hi = _batch(CFG, 56, kernel="wave", seed=2, game_offset=40).init_tables(); hi.run(4)
+    assert np.array_equal(full.tables_numpy(), np.concatenate([lo.tables_numpy(), hi.tables_numpy()]))
+    assert np.array_equal(full.counters_numpy(), np.concatenate([lo.counters_numpy(), hi.counters_numpy()]))
+
+
+HETERO = {"agents": [dict(CFG_AGENT, gamma=0.35, alpha=0.5, epsilon=0.8), dict(CFG_AGENT)],
+          "environment": dict(CFG_ENV, noise_prob=0.05)}
+BUFFER = {"agents": [dict(CFG_AGENT, min_memory=70, capacity=90), dict(CFG_AGENT, min_memory=100, capacity=80)],
+          "environment": dict(CFG_ENV, max_steps=30)}
+THREE = {"agents": [dict(CFG_AGENT, actions=11, states=50, action_range=[0.1, 0.3], min_memory=25),
+                    dict(CFG_AGENT, actions=21, states=100, action_range=[0.15, 0.35], min_memory=25),
+                    dict(CFG_AGENT, actions=5, states=20, action_range=[0.0, 0.3], min_memory=25, max_state=10)],
+         "environment": dict(CFG_ENV, nplayers=3, max_steps=25)}
+CAP64 = {"agents": [dict(CFG_AGENT, min_memory=20, capacity=64), dict(CFG_AGENT)], "environment": dict(CFG_ENV)}
+
+
+@pytest.mark.parametrize("name,config,dtype", [
+    ("hetero_noise", HETERO, "float64"), ("hetero_noise", HETERO, "float32"),
+    ("buffer_T30", BUFFER, "float64"), ("three_players", THREE, "float64"), ("capacity64", CAP64, "float32")])
+def test_generic_philox_other_configs_vs_oracle(name, config, dtype):
+    """Noise, heterogeneous agents, 3 players with different grids, buffers that
+    span episodes / overflow: generic kernel vs oracle, bit for bit, two calls."""
+    G, qd = 37, (1 if dtype == "float64" else 0)
+    gb = _batch(config, G, dtype=dtype, seed=4).init_tables()
+    assert gb.planned_kernel() == "generic"
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    o1 = gb.run(5, per_game_logs=True)
+    o2 = gb.run(4, per_game_logs=True)
+    q, c, s, eps, mem, oo1 = _oracle_run(config, G, qd, q0, s0, 5, seed=4)
+    cfg, _ = O.cfg_from_config(config, G, qd)
+    oo2 = O.episodes(cfg, q, c, s, eps, mem, 4, seed=4, first_episode=5)
+    assert np.array_equal(gb.tables_numpy(), q)
+    assert np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    assert np.array_equal(o1["game_reward_log"], oo1["game_reward_log"])
+    assert np.array_equal(o2["game_action_log"], oo2["game_action_log"])
+    assert list(gb.mem_count[:gb.N]) == list(mem.count[:gb.N])
+
+
+def test_play_greedy_vs_oracle():
+    gb = _batch(CFG, 64, dtype="float32", seed=1).init_tables()
+    gb.run(3)
+    mr, ma = gb.play_greedy(iters=2)
+    cfg, _ = O.cfg_from_config(CFG, 64, 0)
+    omr, oma = O.play_greedy(cfg, gb.tables_numpy(), 2, seed=1)
+    assert np.array_equal(mr, omr) and np.array_equal(ma, oma)
+    st0 = np.random.RandomState(0).uniform(0, 10, (2, 64))
+    mr, ma = gb.play_greedy(iters=2, state0=st0)
+    omr, oma = O.play_greedy(cfg, gb.tables_numpy(), 2, state0=np.ascontiguousarray(st0))
+    assert np.array_equal(mr, omr) and np.array_equal(ma, oma)
+
+
+def test_wave_forced_on_unsupported_config_fails_loudly():
+    from th_rl_amd._lib import ThrlError
+    gb = _batch(HETERO, 8, dtype="float32", kernel="wave").init_tables()
+    with pytest.raises(ThrlError, match="wave kernel cannot run"):
+        gb.run(1)
+    with pytest.raises(ThrlError):
+        _batch(CFG, 8, dtype="float64", kernel="wave").init_tables().run(1)
+
+
+def test_full_size_properties_65536_games():
+    """BASELINE config[1] size: properties that do not need the oracle.  Every agent
+    makes exactly E*T visits; tables stay finite; wave == generic on device."""
+    import torch
+    G, E = 65536, 6
+    a = _batch(CFG, G, kernel="wave", seed=3).init_tables()
+    b = _batch(CFG, G, kernel="generic", seed=3).init_tables()
+    ra = a.run(E); rb = b.run(E)
+    assert ra["kernel"] == "wave"
+    half = a.stride // 2
+    assert bool((a.counter[:, :half].sum(dim=1) == E * 100).all())
+    assert bool((a.counter[:, half:].sum(dim=1) == E * 100).all())
+    assert bool(torch.isfinite(a.q).all())
+    assert torch.equal(a.q, b.q) and torch.equal(a.counter, b.counter) and torch.equal(a.state, b.state)
+    np.testing.assert_allclose(ra["reward_log"], rb["reward_log"], rtol=1e-12)
+    # prices live on the action grid: 6 - 0.1*(k0+k1)
+    st = a.states_numpy()
+    assert st.min() >= 2.0 - 1e-9 and st.max() <= 6.0 + 1e-9
+    # sanity band of the early learning curve (reward per agent between Nash-ish and cartel)
+    assert 9.0 < ra["reward_log"].mean() < 12.6
+
+
+def test_full_size_properties_1M_games():
+    """BASELINE config[2] size (2^20 games): visit-count and finiteness invariants."""
+    import torch
+    G, E = 1 << 20, 3
+    a = _batch(CFG, G, kernel="wave", seed=8).init_tables()
+    r = a.run(E)
+    assert r["kernel"] == "wave"
+    half = a.stride // 2
+    assert bool((a.counter[:, :half].sum(dim=1) == E * 100).all())
+    assert bool((a.counter[:, half:].sum(dim=1) == E * 100).all())
+    assert bool(torch.isfinite(a.q).all())
+    assert 9.0 < r["reward_log"].mean() < 12.6

@@ -1,0 +1,204 @@
+"""Agents of the reference (th_rl/agents.py) with the same constructors and protocol.
+
+QTable is the hot-path agent.  Its object-level methods run on the GPU through the
+unfused operators of libthrl_hip.so (one game per call); training many games at
+once goes through GameBatch / train_one instead.  Host-side state (`table`,
+`counter`, `epsilon`, `memory`) keeps the reference's attribute names so
+utils.load_experiment / plot_qagent style consumers keep working.
+
+The neural agents (Reinforce / ActorCritic / CAC) are constructible so that the
+reference's example configs load, but their compute methods are not part of this
+round's scope and raise NotImplementedError.
+"""
+from collections import namedtuple
+import random
+
+import numpy
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import _lib
+from .buffers import *  # noqa: F401,F403  (the buffer class name is eval'd, as in the reference)
+
+
+class QTable:
+    def __init__(
+        self,
+        states=16,
+        actions=4,
+        action_range=[0, 1],
+        gamma=0.99,
+        buffer="ReplayBuffer",
+        capacity=500,
+        max_state=10,
+        alpha=0.1,
+        eps_end=2e-2,
+        epsilon=0.5,
+        eps_step=5e-4,
+        min_memory=100,
+        **kwargs
+    ):
+        self.table = 12.5 / (1 - gamma) + numpy.random.randn(states + 1, actions)
+        self.gamma = gamma
+        self.alpha = alpha
+        self.action_space = numpy.arange(0, actions)
+        self.action_range = action_range
+        self.actions = actions
+        self.epsilon = epsilon
+        self.eps_step = eps_step
+        self.eps_end = eps_end
+        self.states = states
+        self.max_state = max_state
+        self.min_memory = min_memory
+        self.capacity = capacity
+        self.experience = namedtuple(
+            "Experience", field_names=["state", "action", "reward", "done", "new_state"]
+        )
+        self.memory = eval(buffer)(capacity, self.experience)
+        self.counter = 0 * self.table
+        self._ops = None
+
+    # -- device plumbing ---------------------------------------------------------
+    def config_block(self):
+        """The JSON block that reconstructs this agent (used to build thrl_cfg)."""
+        return dict(name="QTable", states=self.states, actions=self.actions,
+                    action_range=list(self.action_range), gamma=self.gamma, capacity=self.capacity,
+                    max_state=self.max_state, alpha=self.alpha, eps_end=self.eps_end,
+                    epsilon=self.epsilon, eps_step=self.eps_step, min_memory=self.min_memory)
+
+    def _device_ops(self):
+        from ._ops import DeviceOps
+        cfg, _ = _lib.cfg_from_config(
+            {"agents": [self.config_block()], "environment": {"nplayers": 1, "max_steps": 1}}, 1, 1)
+        if self._ops is None:
+            self._ops = DeviceOps(cfg)
+        self._ops.cfg = cfg
+        return self._ops
+
+    # -- reference protocol ------------------------------------------------------
+    def encode(self, state):
+        state = numpy.asarray(state)
+        rows = self._device_ops().encode(0, state.astype("float64"), state.dtype == numpy.float32)
+        return rows.reshape(state.shape)
+
+    def scale(self, actions):
+        return self._device_ops().scale(0, actions)
+
+    def sample_action(self, state):
+        """epsilon-greedy; the two stdlib draws are made exactly where the reference makes them."""
+        if random.uniform(0, 1) < self.epsilon:
+            return random.choice(self.action_space)
+        st = state.numpy() if isinstance(state, torch.Tensor) else numpy.asarray(state)
+        return self._greedy(st)
+
+    def get_action(self, state):
+        return self._greedy(numpy.asarray(state))
+
+    def _greedy(self, st):
+        price = float(numpy.asarray(st).reshape(-1)[0])
+        return numpy.int64(self._device_ops().greedy_action(0, self.table, price, st.dtype == numpy.float32))
+
+    def train_net(self):
+        if len(self.memory) >= self.min_memory:
+            price, acts, rwrd, not_done, next_state = self.memory.replay()
+            price = numpy.array(price, dtype="float64").reshape(-1)
+            next_state = numpy.array(next_state, dtype="float64").reshape(-1)
+            acts = numpy.reshape(acts, [-1])
+            rwrd = numpy.reshape(rwrd, [-1]).astype("float64")
+            self.table, counter = self._device_ops().td_update(
+                0, self.table, numpy.zeros_like(self.table), price, acts, rwrd, next_state)
+            self.counter = self.counter + counter
+            self.memory.empty()
+        self.epsilon = self.eps_end + (self.epsilon - self.eps_end) * self.eps_step
+
+    def reset(self, eps_end):
+        self.table = 100 / (1 - self.gamma) + numpy.random.randn(self.states, self.actions)
+        self.epsilon = 1.0
+        self.eps_end = eps_end
+
+    def reset_value(self, eps_end):
+        self.table = 100 / (1 - self.gamma) + numpy.random.randn(self.states, self.actions)
+
+    def reset_pi(self, eps_end):
+        self.epsilon = 1.0
+        self.eps_end = eps_end
+
+    def save(self, loc):
+        numpy.save(loc, self.table)
+        numpy.save(loc + "_counter", self.counter)
+
+    def load(self, loc):
+        self.table = numpy.load(loc + ".npy")
+        self.counter = numpy.load(loc + "_counter.npy")
+
+
+class _NeuralAgentBase(nn.Module):
+    """Constructor-compatible shell for the reference's torch agents: parameters and
+    save/load work (so configs and stored runs load); acting/learning is out of scope."""
+
+    _scope_note = ("neural agents are outside this round's hot path (SURVEY.md section 8f, rank 3); "
+                   "only QTable agents train on the device")
+
+    def _common(self, actions, action_range, gamma, buffer, capacity, min_memory, entropy):
+        self.gamma = gamma
+        self.action_range = action_range
+        self.actions = actions
+        self.experience = namedtuple(
+            "Experience", field_names=["state", "action", "reward", "done", "new_state"]
+        )
+        self.cast = [torch.float, torch.int64, torch.float, torch.float, torch.float]
+        self.memory = eval(buffer)(capacity, self.experience)
+        self.min_memory = min_memory
+        self.entropy = entropy
+
+    def scale(self, action):
+        return action / self.actions * (self.action_range[1] - self.action_range[0]) + self.action_range[0]
+
+    def sample_action(self, state):
+        raise NotImplementedError(self._scope_note)
+
+    def get_action(self, state):
+        raise NotImplementedError(self._scope_note)
+
+    def train_net(self):
+        raise NotImplementedError(self._scope_note)
+
+    def save(self, loc):
+        torch.save(self.state_dict(), loc)
+
+    def load(self, loc):
+        self.load_state_dict(torch.load(loc, weights_only=True))
+
+
+class Reinforce(_NeuralAgentBase):
+    def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
+                 capacity=50000, min_memory=1000, entropy=0, **kwargs):
+        super().__init__()
+        self.fc1 = nn.Linear(states, 256)
+        self.fc_pi = nn.Linear(256, actions)
+        self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
+        self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
+
+
+class ActorCritic(_NeuralAgentBase):
+    def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
+                 capacity=50000, min_memory=1000, entropy=0, **kwargs):
+        super().__init__()
+        self.fc1 = nn.Linear(states, 256)
+        self.fc_pi = nn.Linear(256, actions)
+        self.fc_v = nn.Linear(256, 1)
+        self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
+        self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
+
+
+class CAC(_NeuralAgentBase):
+    def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
+                 capacity=50000, min_memory=1000, entropy=0, **kwargs):
+        super().__init__()
+        self.fc1 = nn.Linear(states, 256)
+        self.fc_mu = nn.Linear(256, 1)
+        self.fc_std = nn.Linear(256, 1)
+        self.fc_v = nn.Linear(256, 1)
+        self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
+        self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)

@@ -1,0 +1,477 @@
+// thrl_api.hip -- the extern "C" surface of libthrl_hip.so (see include/thrl.h).
+// Host logic only: validation, kernel selection, launch geometry.  No torch types.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "thrl_kernels.h"
+#include "thrl_wave_lut.h"
+
+using namespace thrl;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(int e, const char* what) {
+    return fail(THRL_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)e));
+}
+
+// ---- host restatements of the tiny scalar formulas (IEEE double/float; this
+// file is built with -ffp-contract=off so they round exactly like the device).
+double h_scale(int k, const thrl_cfg* c, int i) {
+    double x = (double)k / ((double)c->n_actions[i] - 1.0);
+    x = x * (c->act_hi[i] - c->act_lo[i]);
+    return x + c->act_lo[i];
+}
+int h_encode64(double price, const thrl_cfg* c, int i) {
+    return (int)rint(price / c->max_state[i] * (double)c->n_states[i]);
+}
+int h_encode32(double price, const thrl_cfg* c, int i) {
+    float x = (float)price;
+    x = x / (float)c->max_state[i];
+    x = x * (float)c->n_states[i];
+    return (int)rintf(x);
+}
+double h_price(const thrl_cfg* c, const double* scaled) {
+    const double ratio = c->env_a / c->env_b;
+    double Q = 0.0;
+    for (int i = 0; i < c->n_agents; i++) Q = Q + ratio * scaled[i];
+    double p = c->env_a - c->env_b * Q;
+    return p > 0.0 ? p : 0.0;
+}
+
+int validate(const thrl_cfg* c) {
+    if (!c) return fail(THRL_ERR_NULL, "cfg is NULL");
+    if (c->n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", c->n_games);
+    if (c->n_agents < 1 || c->n_agents > THRL_MAXA)
+        return fail(THRL_ERR_BAD_CONFIG, "n_agents=%d out of [1,%d]", c->n_agents, THRL_MAXA);
+    if (c->max_steps < 1) return fail(THRL_ERR_BAD_CONFIG, "max_steps=%d must be >= 1", c->max_steps);
+    if (c->q_dtype != 0 && c->q_dtype != 1) return fail(THRL_ERR_BAD_CONFIG, "q_dtype=%d", c->q_dtype);
+    if (!(c->env_b != 0.0)) return fail(THRL_ERR_BAD_CONFIG, "env_b must be non-zero");
+    for (int i = 0; i < c->n_agents; i++) {
+        if (c->n_states[i] < 1 || c->n_states[i] > 32000)
+            return fail(THRL_ERR_BAD_CONFIG, "agent %d: states=%d out of [1,32000]", i, c->n_states[i]);
+        if (c->n_actions[i] < 2 || c->n_actions[i] > 32000)
+            return fail(THRL_ERR_BAD_CONFIG, "agent %d: actions=%d out of [2,32000]", i, c->n_actions[i]);
+        if (c->capacity[i] < 0 || c->min_memory[i] < 0)
+            return fail(THRL_ERR_BAD_CONFIG, "agent %d: negative capacity/min_memory", i);
+        if (!(c->max_state[i] > 0.0)) return fail(THRL_ERR_BAD_CONFIG, "agent %d: max_state must be > 0", i);
+    }
+    return THRL_OK;
+}
+
+void fill_agents(const thrl_cfg* c, AgentParams* ag, EnvParams* env) {
+    int off = 0;
+    for (int i = 0; i < THRL_MAXA; i++) {
+        AgentParams p;
+        memset(&p, 0, sizeof(p));
+        if (i < c->n_agents) {
+            p.rows = c->n_states[i] + 1;
+            p.n_states = c->n_states[i];
+            p.n_actions = c->n_actions[i];
+            p.min_memory = c->min_memory[i];
+            p.capacity = c->capacity[i];
+            p.table_off = off;
+            off += p.rows * p.n_actions;
+            p.max_state = c->max_state[i];
+            p.max_state_f = (float)c->max_state[i];
+            p.gamma = c->gamma[i]; p.alpha = c->alpha[i];
+            p.one_minus_alpha = 1.0 - c->alpha[i];
+            p.gamma_f = (float)c->gamma[i]; p.alpha_f = (float)c->alpha[i];
+            p.one_minus_alpha_f = (float)(1.0 - c->alpha[i]);
+            p.eps_end = c->eps_end[i]; p.eps_step = c->eps_step[i];
+            p.act_lo = c->act_lo[i]; p.act_span = c->act_hi[i] - c->act_lo[i];
+            p.act_den = (double)c->n_actions[i] - 1.0;
+        }
+        ag[i] = p;
+    }
+    if (env) {
+        env->a = c->env_a; env->b = c->env_b; env->ratio = c->env_a / c->env_b;
+        env->noise_prob = c->noise_prob; env->noise_lo = c->env_a * 0.7;
+    }
+}
+
+// largest number of buffered transitions any agent can hold (bounds the ring)
+int eff_capacity(const thrl_cfg* c, int i) {
+    const int cap = c->capacity[i], mm = c->min_memory[i], T = c->max_steps;
+    if (cap <= 0) return 0;
+    if (cap < mm) return cap;                        // never trains, ring wraps at cap
+    const long need = (long)T * ((mm + T - 1) / T > 0 ? (mm + T - 1) / T : 1);
+    return (int)(need < cap ? need : cap);
+}
+int capmax_of(const thrl_cfg* c) {
+    int m = 1;
+    for (int i = 0; i < c->n_agents; i++) { int e = eff_capacity(c, i); if (e > m) m = e; }
+    return m;
+}
+
+struct WavePlan {
+    bool ok;
+    char why[200];
+    int row_lo, win_rows;
+    int lut_bytes, game_lds_bytes, waves_per_block, blocks_per_cu;
+};
+
+int g_num_cu = 0;
+int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+// Can the fused wave kernel run this config?  (DESIGN.md "wave kernel: eligibility")
+WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
+    WavePlan p;
+    memset(&p, 0, sizeof(p));
+#define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
+    if (c->n_agents != 2) NO("needs exactly 2 agents");
+    if (c->q_dtype != 0) NO("float32 tables only");
+    if (c->noise_prob > 0.0) NO("noise_prob > 0");
+    if (injected) NO("injected draws");
+    if (c->n_states[0] != c->n_states[1] || c->n_actions[0] != c->n_actions[1] ||
+        c->max_state[0] != c->max_state[1]) NO("agents must share the state/action grid sizes");
+    const int A = c->n_actions[0], T = c->max_steps;
+    if (A > 32) NO("actions > 32");
+    if (T > 256) NO("max_steps > 256");
+    for (int i = 0; i < 2; i++) {
+        if (T < c->min_memory[i]) NO("max_steps < min_memory (buffer spans episodes)");
+        if (T > c->capacity[i]) NO("max_steps > capacity (deque overflow)");
+        if (run && run->mem_count[i] != 0) NO("non-empty replay memory on entry");
+    }
+    int lo = 1 << 30, hi = -1;
+    for (int a0 = 0; a0 < A; a0++)
+        for (int a1 = 0; a1 < A; a1++) {
+            const double sc[2] = {h_scale(a0, c, 0), h_scale(a1, c, 1)};
+            const double price = h_price(c, sc);
+            const int r64 = h_encode64(price, c, 0), r32 = h_encode32(price, c, 0);
+            if (r64 != r32) NO("float32 and float64 state encodings differ on the action grid");
+            if (r64 < 0 || r64 > c->n_states[0]) NO("price outside the table on the action grid");
+            if (r64 < lo) lo = r64;
+            if (r64 > hi) hi = r64;
+        }
+    p.row_lo = lo;
+    p.win_rows = hi - lo + 1;
+    if (p.win_rows + 2 > 128) NO("reachable row window > 126 rows");
+    const WaveLut L = wave_lut_layout(A);
+    p.lut_bytes = L.bytes;
+    p.game_lds_bytes = 2 * (p.win_rows + 2) * A * 4;
+    // choose waves/block to maximise resident waves per CU (LDS-bound), block LDS <= 64 KiB
+    int best_w = 0, best_total = 0, best_b = 0;
+    for (int w = 1; w <= 16; w++) {
+        const int lds = p.lut_bytes + w * p.game_lds_bytes;
+        if (lds > 65536) break;
+        int b = 163840 / (((lds + 511) / 512) * 512);
+        if (b * w > 32) b = 32 / w;
+        if (b < 1) continue;
+        const int total = b * w;
+        if (total > best_total || (total == best_total && w < best_w)) { best_total = total; best_w = w; best_b = b; }
+    }
+    if (best_w == 0) NO("table window does not fit LDS");
+    p.waves_per_block = best_w;
+    p.blocks_per_cu = best_b;
+    p.ok = true;
+    return p;
+#undef NO
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
+constexpr size_t kMaxWaves = 256 * 32 * 2;      // partials for up to 16384 waves
+
+}  // namespace
+
+extern "C" {
+
+int thrl_version(void) { return THRL_ABI_VERSION; }
+const char* thrl_last_error(void) { return g_err; }
+
+size_t thrl_table_stride(const thrl_cfg* c) {
+    if (!c || c->n_agents < 1 || c->n_agents > THRL_MAXA) return 0;
+    size_t s = 0;
+    for (int i = 0; i < c->n_agents; i++) s += (size_t)(c->n_states[i] + 1) * (size_t)c->n_actions[i];
+    return s;
+}
+size_t thrl_table_offset(const thrl_cfg* c, int agent) {
+    if (!c || agent < 0 || agent > c->n_agents) return 0;
+    size_t s = 0;
+    for (int i = 0; i < agent; i++) s += (size_t)(c->n_states[i] + 1) * (size_t)c->n_actions[i];
+    return s;
+}
+size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
+    if (validate(c) != THRL_OK) return 0;
+    const size_t n = (size_t)capmax_of(c) * (size_t)c->n_agents * (size_t)c->n_games;
+    return align_up(n * 2, 256) * 3 + align_up(n * 8, 256) * 2;
+}
+size_t thrl_workspace_bytes(const thrl_cfg* c) {
+    (void)c;
+    return kLutRegion + kMaxWaves * 64 * sizeof(double);
+}
+int thrl_select_kernel(const thrl_cfg* c, int injected) {
+    if (validate(c) != THRL_OK) return THRL_ERR_BAD_CONFIG;
+    const WavePlan p = plan_wave(c, nullptr, injected != 0);
+    if (!p.ok) { snprintf(g_err, sizeof(g_err), "generic kernel: %s", p.why); return THRL_KERNEL_GENERIC; }
+    return THRL_KERNEL_WAVE;
+}
+
+int thrl_qtable_init(const thrl_cfg* c, void* q, int32_t* counter, double* state, uint64_t seed,
+                     uint64_t game_offset, void* stream) {
+    int rc = validate(c);
+    if (rc) return rc;
+    if (!q || !state) return fail(THRL_ERR_NULL, "q/state is NULL");
+    InitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.N = c->n_agents; a.stride = (int64_t)thrl_table_stride(c); a.env_a = c->env_a;
+    fill_agents(c, a.ag, nullptr);
+    a.q = q; a.counter = counter; a.state = state; a.seed = seed; a.game_offset = game_offset;
+    const int e = launch_init(a, c->q_dtype, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_init launch") : THRL_OK;
+}
+
+static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, hipStream_t s) {
+    const int capmax = capmax_of(c);
+    const size_t need = thrl_replay_mem_bytes(c);
+    if (!b->replay_mem || b->replay_mem_bytes < need)
+        return fail(THRL_ERR_WORKSPACE, "replay_mem too small: have %zu need %zu", b->replay_mem_bytes, need);
+    const bool injected = b->inj_u != nullptr;
+    if (injected && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
+    if (injected && c->noise_prob > 0.0 && (!b->inj_noise_u || !b->inj_noise_a))
+        return fail(THRL_ERR_NULL, "noise_prob > 0 with injected draws needs inj_noise_u/inj_noise_a");
+    GenericArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.N = c->n_agents; a.T = c->max_steps; a.capmax = capmax;
+    a.stride = (int64_t)thrl_table_stride(c);
+    fill_agents(c, a.ag, &a.env);
+    a.q = b->q; a.counter = b->counter; a.state = b->state;
+    {
+        const size_t n = (size_t)capmax * (size_t)c->n_agents * (size_t)c->n_games;
+        char* base = (char*)b->replay_mem;
+        const size_t s2 = align_up(n * 2, 256), s8 = align_up(n * 8, 256);
+        a.mem.s = (int16_t*)base; a.mem.ns = (int16_t*)(base + s2); a.mem.a = (int16_t*)(base + 2 * s2);
+        a.mem.r = (double*)(base + 3 * s2); a.mem.ov = (double*)(base + 3 * s2 + s8);
+    }
+    a.sum_reward = b->reward_log; a.sum_action = b->action_log;
+    if ((a.sum_reward == nullptr) != (a.sum_action == nullptr))
+        return fail(THRL_ERR_NULL, "reward_log and action_log must both be given or both NULL");
+    a.game_reward_log = b->game_reward_log; a.game_action_log = b->game_action_log;
+    a.inj_u = b->inj_u; a.inj_choice = b->inj_choice; a.inj_noise_u = b->inj_noise_u; a.inj_noise_a = b->inj_noise_a;
+    a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
+    a.n_episodes = run->n_episodes;
+    for (int i = 0; i < THRL_MAXA; i++) { a.eps0[i] = run->eps[i]; a.cnt0[i] = run->mem_count[i]; }
+    const int nlog = run->n_episodes * c->n_agents;
+    if (a.sum_reward) {
+        hipError_t e1 = hipMemsetAsync(a.sum_reward, 0, sizeof(double) * nlog, s);
+        hipError_t e2 = hipMemsetAsync(a.sum_action, 0, sizeof(double) * nlog, s);
+        if (e1 != hipSuccess || e2 != hipSuccess) return hip_fail(e1 != hipSuccess ? e1 : e2, "log memset");
+    }
+    int e = launch_generic(a, c->q_dtype, s);
+    if (e) return hip_fail(e, "k_generic_episodes launch");
+    if (a.sum_reward) {
+        e = launch_finalize_logs(a.sum_reward, a.sum_action, nlog, c->n_games, s);
+        if (e) return hip_fail(e, "k_finalize_logs launch");
+    }
+    // host mirror of the per-episode bookkeeping that is identical for all games
+    for (int ep = 0; ep < run->n_episodes; ep++)
+        for (int i = 0; i < c->n_agents; i++) {
+            const int cap = c->capacity[i];
+            if (cap > 0)
+                for (int t = 0; t < c->max_steps; t++) {
+                    run->mem_count[i] += 1;
+                    if (run->mem_count[i] >= 2 * cap) run->mem_count[i] -= cap;
+                }
+            const int len = run->mem_count[i] < cap ? run->mem_count[i] : cap;
+            if (len >= c->min_memory[i]) run->mem_count[i] = 0;
+            run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];
+        }
+    run->kernel_used = THRL_KERNEL_GENERIC;
+    return THRL_OK;
+}
+
+static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, const WavePlan& p, hipStream_t s) {
+    if (!b->workspace || b->workspace_bytes < thrl_workspace_bytes(c))
+        return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes,
+                    thrl_workspace_bytes(c));
+    if (p.lut_bytes > (int)kLutRegion) return fail(THRL_ERR_UNSUPPORTED, "LUT image too large");
+    WaveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.T = c->max_steps; a.A = c->n_actions[0]; a.rows = c->n_states[0] + 1;
+    a.row_lo = p.row_lo; a.win_rows = p.win_rows;
+    a.waves_per_block = p.waves_per_block;
+    a.lut_bytes = p.lut_bytes; a.game_lds_bytes = p.game_lds_bytes;
+    a.stride = (int64_t)thrl_table_stride(c);
+    AgentParams ag[THRL_MAXA];
+    fill_agents(c, ag, &a.env);
+    a.ag[0] = ag[0]; a.ag[1] = ag[1];
+    a.q = (float*)b->q; a.counter = b->counter; a.state = b->state;
+    unsigned char* lut = (unsigned char*)b->workspace;
+    a.lut_ns = lut;
+    a.partial = (double*)((char*)b->workspace + kLutRegion);
+    a.seed = run->seed; a.game_offset = run->game_offset;
+
+    const int block = p.waves_per_block * 64;
+    int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
+    const int max_grid = num_cu() * p.blocks_per_cu;
+    if (grid > max_grid) grid = max_grid;
+    a.total_waves = grid * p.waves_per_block;
+    if ((size_t)a.total_waves > kMaxWaves) return fail(THRL_ERR_WORKSPACE, "too many waves for workspace");
+    const size_t lds = (size_t)p.lut_bytes + (size_t)p.waves_per_block * p.game_lds_bytes;
+
+    int e = launch_wave_lut(a, lut, s);
+    if (e) return hip_fail(e, "k_wave_lut launch");
+    int done = 0;
+    while (done < run->n_episodes) {
+        const int n = run->n_episodes - done < kWaveMaxEpisodes ? run->n_episodes - done : kWaveMaxEpisodes;
+        a.n_episodes = n;
+        a.first_episode = run->first_episode + (uint64_t)done;
+        for (int ep = 0; ep < n; ep++)
+            for (int i = 0; i < 2; i++) {
+                a.eps[ep][i] = run->eps[i];
+                run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];
+            }
+        e = launch_wave(a, grid, block, lds, s);
+        if (e) return hip_fail(e, "k_wave_episodes launch");
+        if (b->reward_log || b->action_log) {
+            e = launch_wave_reduce(a.partial, a.total_waves, n, c->n_games,
+                                   b->reward_log ? b->reward_log + (size_t)done * 2 : nullptr,
+                                   b->action_log ? b->action_log + (size_t)done * 2 : nullptr, s);
+            if (e) return hip_fail(e, "k_wave_reduce launch");
+        }
+        done += n;
+    }
+    run->kernel_used = THRL_KERNEL_WAVE;
+    return THRL_OK;
+}
+
+int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, void* stream) {
+    int rc = validate(c);
+    if (rc) return rc;
+    if (!b || !run) return fail(THRL_ERR_NULL, "bufs/run is NULL");
+    if (!b->q || !b->state) return fail(THRL_ERR_NULL, "q/state is NULL");
+    if (run->n_episodes < 0) return fail(THRL_ERR_BAD_CONFIG, "n_episodes < 0");
+    run->kernel_used = 0;
+    if (run->n_episodes == 0) return THRL_OK;
+    const bool injected = b->inj_u != nullptr;
+    const bool per_game_logs = b->game_reward_log || b->game_action_log;
+    int k = run->kernel;
+    if (k != THRL_KERNEL_AUTO && k != THRL_KERNEL_GENERIC && k != THRL_KERNEL_WAVE)
+        return fail(THRL_ERR_BAD_CONFIG, "unknown kernel id %d", k);
+    if (k != THRL_KERNEL_GENERIC) {
+        WavePlan p = plan_wave(c, run, injected);
+        if (p.ok && per_game_logs) { p.ok = false; snprintf(p.why, sizeof(p.why), "per-game logs requested"); }
+        if (p.ok) return run_wave(c, b, run, p, (hipStream_t)stream);
+        if (k == THRL_KERNEL_WAVE) return fail(THRL_ERR_UNSUPPORTED, "wave kernel cannot run this config: %s", p.why);
+    }
+    return run_generic(c, b, run, (hipStream_t)stream);
+}
+
+int thrl_play_greedy(const thrl_cfg* c, const void* q, const double* state0, int32_t iters, uint64_t seed,
+                     uint64_t game_offset, double* mean_reward, double* mean_action, void* stream) {
+    int rc = validate(c);
+    if (rc) return rc;
+    if (!q || !mean_reward || !mean_action) return fail(THRL_ERR_NULL, "q/mean_reward/mean_action is NULL");
+    if (iters < 0) return fail(THRL_ERR_BAD_CONFIG, "iters < 0");
+    if (iters == 0) return THRL_OK;
+    PlayArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.N = c->n_agents; a.T = c->max_steps; a.iters = iters;
+    a.stride = (int64_t)thrl_table_stride(c);
+    fill_agents(c, a.ag, &a.env);
+    a.q = q; a.state0 = state0; a.mean_reward = mean_reward; a.mean_action = mean_action;
+    a.seed = seed; a.game_offset = game_offset;
+    const int e = launch_play(a, c->q_dtype, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_play_greedy launch") : THRL_OK;
+}
+
+static int op_common(const thrl_cfg* c, OpArgs* a) {
+    int rc = validate(c);
+    if (rc) return rc;
+    memset(a, 0, sizeof(*a));
+    a->G = c->n_games; a->N = c->n_agents; a->stride = (int64_t)thrl_table_stride(c);
+    fill_agents(c, a->ag, &a->env);
+    return THRL_OK;
+}
+
+int thrl_op_sample_action(const thrl_cfg* c, int agent, const void* q, const double* price, double eps,
+                          const double* u, const int8_t* choice, int encode32, int32_t* action_out,
+                          void* stream) {
+    OpArgs a;
+    int rc = op_common(c, &a);
+    if (rc) return rc;
+    if (agent < 0 || agent >= c->n_agents) return fail(THRL_ERR_BAD_CONFIG, "agent %d out of range", agent);
+    if (!q || !price || !action_out) return fail(THRL_ERR_NULL, "q/price/action_out is NULL");
+    if (u && !choice) return fail(THRL_ERR_NULL, "u given without choice");
+    a.agent = agent; a.q = const_cast<void*>(q); a.price = price; a.eps = eps; a.u = u; a.choice = choice;
+    a.encode32 = encode32; a.action_out = action_out;
+    const int e = launch_op_sample(a, c->q_dtype, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_sample launch") : THRL_OK;
+}
+
+int thrl_op_encode(const thrl_cfg* c, int agent, const double* price, int as_float32, int32_t* row_out,
+                   void* stream) {
+    OpArgs a;
+    int rc = op_common(c, &a);
+    if (rc) return rc;
+    if (agent < 0 || agent >= c->n_agents) return fail(THRL_ERR_BAD_CONFIG, "agent %d out of range", agent);
+    if (!price || !row_out) return fail(THRL_ERR_NULL, "price/row_out is NULL");
+    a.agent = agent; a.price = price; a.encode32 = as_float32; a.action_out = row_out;
+    const int e = launch_op_encode(a, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_encode launch") : THRL_OK;
+}
+
+int thrl_op_scale(const thrl_cfg* c, int agent, const int32_t* action, double* scaled_out, void* stream) {
+    OpArgs a;
+    int rc = op_common(c, &a);
+    if (rc) return rc;
+    if (agent < 0 || agent >= c->n_agents) return fail(THRL_ERR_BAD_CONFIG, "agent %d out of range", agent);
+    if (!action || !scaled_out) return fail(THRL_ERR_NULL, "action/scaled_out is NULL");
+    a.agent = agent; a.action = action; a.scaled_out = scaled_out;
+    const int e = launch_op_scale(a, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_scale launch") : THRL_OK;
+}
+
+int thrl_op_env_step(const thrl_cfg* c, const double* scaled, const double* noise_u, const double* noise_a,
+                     double* price_out, double* reward_out, void* stream) {
+    OpArgs a;
+    int rc = op_common(c, &a);
+    if (rc) return rc;
+    if (!scaled || !price_out || !reward_out) return fail(THRL_ERR_NULL, "scaled/price_out/reward_out is NULL");
+    if (noise_u && !noise_a) return fail(THRL_ERR_NULL, "noise_u given without noise_a");
+    a.scaled = scaled; a.noise_u = noise_u; a.noise_a = noise_a; a.price_out = price_out;
+    a.reward_out = reward_out;
+    const int e = launch_op_env_step(a, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_env_step launch") : THRL_OK;
+}
+
+int thrl_op_td_update(const thrl_cfg* c, int agent, void* q, int32_t* counter, int32_t n, const double* price,
+                      const int32_t* action, const double* reward, const double* next_price, double* scratch,
+                      void* stream) {
+    OpArgs a;
+    int rc = op_common(c, &a);
+    if (rc) return rc;
+    if (agent < 0 || agent >= c->n_agents) return fail(THRL_ERR_BAD_CONFIG, "agent %d out of range", agent);
+    if (n < 0) return fail(THRL_ERR_BAD_CONFIG, "n < 0");
+    if (n == 0) return THRL_OK;
+    if (!q || !price || !action || !reward || !next_price || !scratch)
+        return fail(THRL_ERR_NULL, "a required pointer is NULL");
+    a.agent = agent; a.q = q; a.counter = counter; a.n = n; a.price = price; a.action = action;
+    a.reward = reward; a.next_price = next_price; a.reward_out = scratch;
+    const int e = launch_op_td(a, c->q_dtype, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_td launch") : THRL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// thrl_kernels.h -- kernel argument blocks + host-side launchers (internal).
+#pragma once
+#include "thrl_device.h"
+
+namespace thrl {
+
+// Replay memory (ReplayBuffer contents, buffers.py) as structure-of-arrays,
+// entry-major / game-minor so a wave's accesses coalesce: [capmax][N][G].
+struct ReplayMem {
+    int16_t* s;    // encode64(state)       (agents.py:62)
+    int16_t* ns;   // encode64(next_state)  (agents.py:66)
+    int16_t* a;    // action index
+    double*  r;    // reward (float64 as stored by trainer.py:62)
+    double*  ov;   // scratch: old_value snapshot (agents.py:67)
+};
+
+struct GenericArgs {
+    int32_t G, N, T, capmax;
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[THRL_MAXA];
+    void* q;
+    int32_t* counter;
+    double* state;
+    ReplayMem mem;
+    double* sum_reward;        // [E][N] sums over games (finalised to means afterwards) or null
+    double* sum_action;
+    double* game_reward_log;   // [E][N][G] or null
+    double* game_action_log;
+    const double* inj_u;
+    const int8_t* inj_choice;
+    const double* inj_noise_u;
+    const double* inj_noise_a;
+    uint64_t seed, game_offset, first_episode;
+    int32_t n_episodes;
+    double eps0[THRL_MAXA];
+    int32_t cnt0[THRL_MAXA];
+};
+
+// ---- fused wave-per-game kernel (thrl_wave.hip) -----------------------------
+constexpr int kWaveMaxEpisodes = 16;   // 16 episodes x 4 log values = the 64 lanes of the accumulator
+
+struct WaveArgs {
+    int32_t G, T, A, rows;          // homogeneous 2-agent game
+    int32_t row_lo, win_rows;       // LDS window = rows [row_lo, row_lo+win_rows) + 1 spill row
+    int32_t n_episodes;
+    int32_t waves_per_block;
+    int32_t total_waves;
+    int32_t lut_bytes;              // LDS bytes of the payoff LUT region
+    int32_t game_lds_bytes;         // LDS bytes per wave (tables)
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[2];
+    float* q;
+    int32_t* counter;
+    double* state;
+    const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
+    double* partial;                // device [total_waves][E][4] per-wave log sums
+    uint64_t seed, game_offset, first_episode;
+    double eps[kWaveMaxEpisodes][2];
+};
+
+int launch_generic(const GenericArgs& a, int q_dtype, hipStream_t s);
+int launch_finalize_logs(double* sum_reward, double* sum_action, int n, int G, hipStream_t s);
+int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s);
+int launch_wave(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G,
+                       double* reward_log, double* action_log, hipStream_t s);
+
+struct InitArgs {
+    int32_t G, N;
+    int64_t stride;
+    double env_a;
+    AgentParams ag[THRL_MAXA];
+    void* q; int32_t* counter; double* state;
+    uint64_t seed, game_offset;
+};
+int launch_init(const InitArgs& a, int q_dtype, hipStream_t s);
+
+struct PlayArgs {
+    int32_t G, N, T, iters;
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[THRL_MAXA];
+    const void* q;
+    const double* state0;
+    double* mean_reward; double* mean_action;
+    uint64_t seed, game_offset;
+};
+int launch_play(const PlayArgs& a, int q_dtype, hipStream_t s);
+
+struct OpArgs {
+    int32_t G, N, agent, n, encode32;
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[THRL_MAXA];
+    void* q; int32_t* counter;
+    const double* price; const double* next_price; const double* u; const int8_t* choice;
+    const int32_t* action; const double* reward; const double* noise_u; const double* noise_a;
+    const double* scaled;
+    double eps;
+    int32_t* action_out; double* price_out; double* reward_out; double* scaled_out;
+};
+int launch_op_sample(const OpArgs& a, int q_dtype, hipStream_t s);
+int launch_op_env_step(const OpArgs& a, hipStream_t s);
+int launch_op_scale(const OpArgs& a, hipStream_t s);
+int launch_op_encode(const OpArgs& a, hipStream_t s);
+int launch_op_td(const OpArgs& a, int q_dtype, hipStream_t s);
+
+}  // namespace thrl

@@ -1,0 +1,344 @@
+// thrl_wave.hip -- fused episode kernel for gfx950: ONE WAVEFRONT PER GAME.
+//
+// The performance path for the reference's headline shape (2 QTable agents on
+// one NoisyPriceState, noise off, float32 tables).  Same semantics as
+// thrl_generic.hip (and bit-identical results to it and to the float32 oracle):
+// trainer.train_one's loop (th_rl/trainer.py:46-70) with QTable.sample_action
+// (agents.py:80-89), scale (:51-57), NoisyPriceState.step (environments.py:25-39),
+// ReplayBuffer append/replay/empty (buffers.py) and QTable.train_net
+// (agents.py:59-78) fused, for `n_episodes` episodes per launch.
+//
+// MI355X mapping (DESIGN.md "wave kernel"):
+//   * a wave owns one game for the whole launch; its two agents' Q-table WINDOWS
+//     (only the rows the payoff grid can reach, + 2 spill rows for an arbitrary
+//     initial state) are streamed coalesced HBM -> LDS once, stay resident for
+//     all episodes of the launch, and are streamed back once;
+//   * lanes 0-31 serve agent 0, lanes 32-63 agent 1; lane l&31 is action column
+//     l&31, so a row max is one ds_read_b32 + 5 DPP v_max steps;
+//   * the discretised action grid (next-state row + price per action pair) is a
+//     LUT staged in LDS once per block ("payoff LUT");
+//   * everything that is not on the serial state->action->state chain is done
+//     lane-parallel over the T steps of an episode (lane = step): Philox draws,
+//     reward / old-value gathers, log sums, visit-counter atomics;
+//   * the serial chains (play: s -> argmax row s -> LUT -> s'; replay: live row
+//     max -> TD write) touch only SGPRs, LDS and a few VALU ops per step.
+#include "thrl_kernels.h"
+#include "thrl_wave_lut.h"
+
+namespace thrl {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+    const int vi = __builtin_bit_cast(int, v);
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, CTRL, ROW_MASK, 0xF, false));
+    return fmaxf(v, o);
+}
+// max over each 32-lane half; the result is valid in lanes 31 and 63 (rows 1 and 3)
+__device__ __forceinline__ float half_max_to_last_lane(float v) {
+    v = dpp_max<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_max<0x141, 0xF>(v);   // row_half_mirror
+    v = dpp_max<0x140, 0xF>(v);   // row_mirror      -> every lane holds its 16-row max
+    v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1,3 -> 32-lane max there
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// builds the payoff LUT image in HBM (copied to LDS by every block)
+__global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned char* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = a.A;
+    const WaveLut L = wave_lut_layout(A);
+    if (idx < A * A) {
+        const int a0 = idx / A, a1 = idx - a0 * A;
+        double scaled[2] = {scale_action(a0, a.ag[0]), scale_action(a1, a.ag[1])};
+        double rew[2];
+        const double price = env_step<2>(a.env, 2, scaled, a.env.a, rew);
+        out[L.ns_off + idx] = (unsigned char)(encode64(price, a.ag[0]) - a.row_lo);
+        reinterpret_cast<double*>(out + L.price_off)[idx] = price;
+    }
+    if (idx < 2 * A) {
+        const int i = idx / A, k = idx - i * A;
+        const double sc = scale_action(k, a.ag[i]);
+        reinterpret_cast<double*>(out + L.aq_off)[idx] = __dmul_rn(a.env.ratio, sc);
+        reinterpret_cast<double*>(out + L.sct_off)[idx] = __ddiv_rn(sc, (double)a.T);
+    }
+}
+
+template <int NSEG, int NRSEG>
+__global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int A = a.A, W = a.win_rows, T = a.T, lo = a.row_lo;
+    const WaveLut L = wave_lut_layout(A);
+
+    {   // stage the payoff LUT once per block
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lut_ns);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        for (int k = threadIdx.x; k < (a.lut_bytes >> 2); k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+    const unsigned char* lut_ns = smem + L.ns_off;
+    const double* lut_price = reinterpret_cast<const double*>(smem + L.price_off);
+    const double* lut_aq = reinterpret_cast<const double*>(smem + L.aq_off);
+    const double* lut_sct = reinterpret_cast<const double*>(smem + L.sct_off);
+
+    float* tab0 = reinterpret_cast<float*>(smem + a.lut_bytes + (size_t)wib * a.game_lds_bytes);
+    float* tab1 = tab0 + (W + 2) * A;
+    const int half = lane >> 5;
+    const int col = min(lane & 31, A - 1);
+    float* tabh_col = (half ? tab1 : tab0) + col;
+
+    const AgentParams& p0 = a.ag[0];
+    const AgentParams& p1 = a.ag[1];
+    const double inv_T_den = (double)T;
+
+    double acc = 0.0;   // lane (e*4+k): sum over this wave's games of episode-e log value k
+    const int wave_gid = blockIdx.x * a.waves_per_block + wib;
+
+    for (int g = wave_gid; g < a.G; g += a.total_waves) {
+        const uint64_t gid = a.game_offset + (uint64_t)g;
+        float* __restrict__ q0 = a.q + (int64_t)g * a.stride + p0.table_off;
+        float* __restrict__ q1 = a.q + (int64_t)g * a.stride + p1.table_off;
+
+        // ---- initial state -> local rows (window or spill)
+        const double price0 = a.state[g];
+        int sp = __builtin_amdgcn_readfirstlane(encode32(price0, p0));
+        int st = __builtin_amdgcn_readfirstlane(encode64(price0, p0));
+        sp = min(max(sp, 0), a.rows - 1);
+        st = min(max(st, 0), a.rows - 1);
+        int spill0 = -1, spill1 = -1, sp_l, st_l;
+        if (sp >= lo && sp < lo + W) sp_l = sp - lo; else { spill0 = sp; sp_l = W; }
+        if (st == sp) st_l = sp_l;
+        else if (st >= lo && st < lo + W) st_l = st - lo;
+        else { spill1 = st; st_l = W + 1; }
+
+        // ---- stream the table windows HBM -> LDS (contiguous, coalesced)
+        {
+            const float* s0 = q0 + lo * A;
+            const float* s1 = q1 + lo * A;
+            const int n = W * A;
+            for (int k = lane; k < n; k += 64) { tab0[k] = s0[k]; tab1[k] = s1[k]; }
+            if (spill0 >= 0 && lane < A) {
+                tab0[W * A + lane] = q0[spill0 * A + lane];
+                tab1[W * A + lane] = q1[spill0 * A + lane];
+            }
+            if (spill1 >= 0 && lane < A) {
+                tab0[(W + 1) * A + lane] = q0[spill1 * A + lane];
+                tab1[(W + 1) * A + lane] = q1[spill1 * A + lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        int s = sp_l;
+        int last_idx = -1;
+        for (int e = 0; e < a.n_episodes; e++) {
+            const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
+            const double eps0 = a.eps[e][0], eps1 = a.eps[e][1];
+            const int st_first = (e == 0) ? st_l : s;
+
+            // ---- (a) greedy action of every local row, lane = row (table is frozen
+            //          during play: agents.py only writes it in train_net)
+            uint32_t am0[NRSEG], am1[NRSEG];
+#pragma unroll
+            for (int k = 0; k < NRSEG; k++) {
+                const int row = min(lane + 64 * k, W + 1);
+                const float* r0 = tab0 + row * A;
+                const float* r1 = tab1 + row * A;
+                float b0 = r0[0], b1 = r1[0];
+                uint32_t i0 = 0, i1 = 0;
+#pragma unroll 4
+                for (int j = 1; j < A; j++) {
+                    const float v0 = r0[j], v1 = r1[j];
+                    if (v0 > b0) { b0 = v0; i0 = j; }
+                    if (v1 > b1) { b1 = v1; i1 = j; }
+                }
+                am0[k] = i0; am1[k] = i1;
+            }
+
+            // ---- (b,c) play: lane-parallel Philox, then the serial state chain
+            uint32_t seq[NSEG];
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int n = min(64, T - seg * 64);
+                const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
+                const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
+                const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
+                const uint32_t rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) |
+                                    (__umulhi(x.w, (uint32_t)A) << 16);
+                uint32_t sq = 0;
+                for (int t = 0; t < n; t++) {
+                    const uint32_t w = readlane_u(rw, t);
+                    uint32_t g0 = readlane_u(am0[0], s & 63), g1 = readlane_u(am1[0], s & 63);
+                    if (NRSEG > 1) {
+                        const uint32_t h0 = readlane_u(am0[NRSEG - 1], s & 63);
+                        const uint32_t h1 = readlane_u(am1[NRSEG - 1], s & 63);
+                        if (s >= 64) { g0 = h0; g1 = h1; }
+                    }
+                    const uint32_t a0 = (w & 1u) ? ((w >> 8) & 0xFFu) : g0;
+                    const uint32_t a1 = (w & 2u) ? ((w >> 16) & 0xFFu) : g1;
+                    sq = (lane == t) ? ((uint32_t)s | (a0 << 8) | (a1 << 16)) : sq;
+                    last_idx = (int)(a0 * (uint32_t)A + a1);
+                    s = __builtin_amdgcn_readfirstlane((int)lut_ns[last_idx]);
+                }
+                seq[seg] = sq;
+            }
+            const int s_end = s;
+
+            // ---- (d) lane-parallel replay prologue (lane = step): rewards, old-value
+            //          snapshot (agents.py:67), log sums, visit counters (agents.py:76)
+            uint32_t pk[NSEG];
+            float re0[NSEG], re1[NSEG], t40[NSEG], t41[NSEG];
+            double lr0 = 0.0, lr1 = 0.0, la0 = 0.0, la1 = 0.0;
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int tt = seg * 64 + lane;
+                const bool valid = tt < T;
+                const uint32_t word = seq[seg];
+                const int my_s = (tt == 0) ? st_first : (int)(word & 0xFFu);
+                const uint32_t a0 = (word >> 8) & 0xFFu, a1 = (word >> 16) & 0xFFu;
+                uint32_t nw = (uint32_t)__shfl_down((int)word, 1, 64);
+                if (seg + 1 < NSEG) { if (lane == 63) nw = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
+                const int ns = (tt + 1 < T) ? (int)(nw & 0xFFu) : s_end;
+                const int idx = valid ? (int)(a0 * (uint32_t)A + a1) : 0;
+                const double price = lut_price[idx];
+                const double r0d = __dmul_rn(price, lut_aq[valid ? a0 : 0]);
+                const double r1d = __dmul_rn(price, lut_aq[A + (valid ? a1 : 0)]);
+                re0[seg] = (float)r0d; re1[seg] = (float)r1d;
+                const int srow = valid ? my_s : 0;
+                const float ov0 = tab0[srow * A + (valid ? a0 : 0)];
+                const float ov1 = tab1[srow * A + (valid ? a1 : 0)];
+                t40[seg] = __fmul_rn(p0.one_minus_alpha_f, ov0);
+                t41[seg] = __fmul_rn(p1.one_minus_alpha_f, ov1);
+                pk[seg] = (uint32_t)srow | ((uint32_t)ns << 8) | (a0 << 16) | (a1 << 24);
+                if (valid) {
+                    lr0 += __ddiv_rn(r0d, inv_T_den); lr1 += __ddiv_rn(r1d, inv_T_den);
+                    la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
+                    if (a.counter) {
+                        const int grow = srow < W ? lo + srow : (srow == W ? spill0 : spill1);
+                        int32_t* cb = a.counter + (int64_t)g * a.stride + grow * A;
+                        atomicAdd(cb + p0.table_off + a0, 1);
+                        atomicAdd(cb + p1.table_off + a1, 1);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- (e) replay chain (agents.py:68-76): live next_max, sequential writes
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int n = min(64, T - seg * 64);
+                for (int t = 0; t < n; t++) {
+                    const uint32_t w = readlane_u(pk[seg], t);
+                    const int stt = (int)(w & 0xFFu), nst = (int)((w >> 8) & 0xFFu);
+                    const int a0 = (int)((w >> 16) & 0xFFu), a1 = (int)(w >> 24);
+                    const float r0 = readlane_f(re0[seg], t), r1 = readlane_f(re1[seg], t);
+                    const float u0 = readlane_f(t40[seg], t), u1 = readlane_f(t41[seg], t);
+                    const float m = half_max_to_last_lane(tabh_col[nst * A]);
+                    const float nm0 = readlane_f(m, 31), nm1 = readlane_f(m, 63);
+                    const float v0 = __fadd_rn(u0, __fmul_rn(p0.alpha_f, __fadd_rn(r0, __fmul_rn(p0.gamma_f, nm0))));
+                    const float v1 = __fadd_rn(u1, __fmul_rn(p1.alpha_f, __fadd_rn(r1, __fmul_rn(p1.gamma_f, nm1))));
+                    if (lane == 0) tab0[stt * A + a0] = v0;
+                    if (lane == 32) tab1[stt * A + a1] = v1;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+
+            // ---- (f) per-episode log sums of this game into the wave accumulator
+            {
+                const double w0 = wave_sum64(lr0), w1 = wave_sum64(lr1);
+                const double w2 = wave_sum64(la0), w3 = wave_sum64(la1);
+                const int k = lane & 3;
+                const double v = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+                if ((lane >> 2) == e) acc += v;
+            }
+        }
+
+        // ---- stream the windows back LDS -> HBM, store the env state
+        {
+            float* d0 = q0 + lo * A;
+            float* d1 = q1 + lo * A;
+            const int n = W * A;
+            for (int k = lane; k < n; k += 64) { d0[k] = tab0[k]; d1[k] = tab1[k]; }
+            if (spill0 >= 0 && lane < A) {
+                q0[spill0 * A + lane] = tab0[W * A + lane];
+                q1[spill0 * A + lane] = tab1[W * A + lane];
+            }
+            if (spill1 >= 0 && lane < A) {
+                q0[spill1 * A + lane] = tab0[(W + 1) * A + lane];
+                q1[spill1 * A + lane] = tab1[(W + 1) * A + lane];
+            }
+            if (lane == 0 && last_idx >= 0) a.state[g] = lut_price[last_idx];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    a.partial[(size_t)wave_gid * 64 + lane] = acc;
+}
+
+// fixed-order reduction of the per-wave partials -> mean logs [E][2]
+__global__ void __launch_bounds__(64) k_wave_reduce(const double* partial, int total_waves, int n_episodes,
+                                                    double G, double* reward_log, double* action_log) {
+    const int lane = threadIdx.x;
+    const int e = lane >> 2, k = lane & 3;
+    if (e >= n_episodes) return;
+    double s = 0.0;
+    for (int w = 0; w < total_waves; w++) s += partial[(size_t)w * 64 + lane];
+    s = __ddiv_rn(s, G);
+    if (k < 2) { if (reward_log) reward_log[e * 2 + k] = s; }
+    else { if (action_log) action_log[e * 2 + (k - 2)] = s; }
+}
+
+template <int NSEG, int NRSEG>
+static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((k_wave_episodes<NSEG, NRSEG>), dim3(grid), dim3(block), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
+    const int n = a.A * a.A > 2 * a.A ? a.A * a.A : 2 * a.A;
+    hipLaunchKernelGGL(k_wave_lut, dim3((n + 255) / 256), dim3(256), 0, s, a, out);
+    return (int)hipGetLastError();
+}
+
+int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    const int nseg = (a.T + 63) / 64;
+    const int nrseg = (a.win_rows + 2 + 63) / 64;
+    if (nrseg == 1) {
+        switch (nseg) {
+            case 1: return launch_wave_t<1, 1>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 1>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 1>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 1>(a, grid, block, lds, s);
+        }
+    } else if (nrseg == 2) {
+        switch (nseg) {
+            case 1: return launch_wave_t<1, 2>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 2>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 2>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 2>(a, grid, block, lds, s);
+        }
+    }
+    return -1;
+}
+
+int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,
+                       double* action_log, hipStream_t s) {
+    hipLaunchKernelGGL(k_wave_reduce, dim3(1), dim3(64), 0, s, partial, total_waves, n_episodes, (double)G,
+                       reward_log, action_log);
+    return (int)hipGetLastError();
+}
+
+}  // namespace thrl
