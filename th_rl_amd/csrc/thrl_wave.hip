@@ -27,20 +27,44 @@
 
 namespace thrl {
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_max(float v) {
-    const int vi = __builtin_bit_cast(int, v);
-    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(vi, vi, CTRL, ROW_MASK, 0xF, false));
-    return fmaxf(v, o);
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+// max over each 32-lane half, result in EVERY lane of the half.
+// 4 single-instruction DPP max steps give each 16-lane row its max; the two rows of
+// a half are then exchanged with v_permlane16_swap (gfx950) and combined.
+// The s_nop 1 before each DPP op are the 2 wait states a DPP read of a
+// just-written VGPR needs (hipcc does not look inside asm statements).
+__device__ __forceinline__ float half_max_all_lanes(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    const unsigned vi = __builtin_bit_cast(unsigned, v);
+    unsigned vj = vi;
+    asm("" : "+v"(vj));      // opaque copy: the swap needs two distinct registers
+    const v2u r = __builtin_amdgcn_permlane16_swap(vi, vj, false, false);
+    // (copy the elements out first: __builtin_bit_cast on r.x / r.y directly resolves
+    //  both to element 0 with this compiler)
+    const unsigned rx = r.x, ry = r.y;
+    float m;
+    asm("s_nop 0\n\tv_max_f32 %0, %1, %2" : "=v"(m) : "v"(__builtin_bit_cast(float, rx)), "v"(__builtin_bit_cast(float, ry)));
+    return m;
 }
-// max over each 32-lane half; the result is valid in lanes 31 and 63 (rows 1 and 3)
-__device__ __forceinline__ float half_max_to_last_lane(float v) {
-    v = dpp_max<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-    v = dpp_max<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-    v = dpp_max<0x141, 0xF>(v);   // row_half_mirror
-    v = dpp_max<0x140, 0xF>(v);   // row_mirror      -> every lane holds its 16-row max
-    v = dpp_max<0x142, 0xA>(v);   // row_bcast15 into rows 1,3 -> 32-lane max there
-    return v;
+
+// lanes<32 of the result: lanes 0-31 of a ; lanes>=32: lanes 0-31 of b   (.x)
+// and the same for the upper halves (.y): one v_permlane32_swap.
+__device__ __forceinline__ v2u pack_halves(unsigned a, unsigned b) {
+    return __builtin_amdgcn_permlane32_swap(a, b, false, false);
+}
+
+__device__ __forceinline__ unsigned bperm(unsigned byte_sel, unsigned v) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_sel, (int)v);
 }
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -52,8 +76,26 @@ __device__ __forceinline__ double wave_sum64(double v) {
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+
+// value of a lane-indexed-by-row register pair at (uniform) row s
+template <int NRSEG>
+__device__ __forceinline__ uint32_t read_row(const uint32_t (&r)[NRSEG], int s) {
+    uint32_t v = readlane_u(r[0], s & 63);
+    if (NRSEG > 1) {
+        const uint32_t h = readlane_u(r[NRSEG - 1], s & 63);
+        if (s >= 64) v = h;
+    }
+    return v;
+}
+// per-lane gather from a lane-indexed-by-row register pair (row differs per lane)
+template <int NRSEG>
+__device__ __forceinline__ uint32_t gather_row(const uint32_t (&r)[NRSEG], uint32_t row) {
+    uint32_t v = bperm((row & 63u) << 2, r[0]);
+    if (NRSEG > 1) {
+        const uint32_t h = bperm((row & 63u) << 2, r[NRSEG - 1]);
+        if (row >= 64u) v = h;
+    }
+    return v;
 }
 
 // builds the payoff LUT image in HBM (copied to LDS by every block)
@@ -101,10 +143,16 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
     const int half = lane >> 5;
     const int col = min(lane & 31, A - 1);
     float* tabh_col = (half ? tab1 : tab0) + col;
+    const unsigned tab0_off = (unsigned)(reinterpret_cast<unsigned char*>(tab0) - smem);
+    const unsigned tab1_off = (unsigned)(reinterpret_cast<unsigned char*>(tab1) - smem);
+    const unsigned sel_base = (unsigned)(lane & 32) << 2;      // bpermute byte index of this half's lane 0
+    const bool writer = (lane & 31) == 0;
 
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
     const double inv_T_den = (double)T;
+    const float gamma_h = half ? p1.gamma_f : p0.gamma_f;
+    const float alpha_h = half ? p1.alpha_f : p0.alpha_f;
 
     double acc = 0.0;   // lane (e*4+k): sum over this wave's games of episode-e log value k
     const int wave_gid = blockIdx.x * a.waves_per_block + wib;
@@ -144,15 +192,16 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         int s = sp_l;
-        int last_idx = -1;
+        double last_price = price0;
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
             const double eps0 = a.eps[e][0], eps1 = a.eps[e][1];
             const int st_first = (e == 0) ? st_l : s;
 
-            // ---- (a) greedy action of every local row, lane = row (table is frozen
-            //          during play: agents.py only writes it in train_net)
-            uint32_t am0[NRSEG], am1[NRSEG];
+            // ---- (a) greedy action of every local row, lane = row (the table is frozen
+            //          during play: agents.py only writes it in train_net), and the
+            //          greedy-greedy successor row of every row
+            uint32_t am0[NRSEG], am1[NRSEG], grow[NRSEG];
 #pragma unroll
             for (int k = 0; k < NRSEG; k++) {
                 const int row = min(lane + 64 * k, W + 1);
@@ -167,10 +216,12 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                     if (v1 > b1) { b1 = v1; i1 = j; }
                 }
                 am0[k] = i0; am1[k] = i1;
+                grow[k] = lut_ns[i0 * (uint32_t)A + i1];
             }
 
-            // ---- (b,c) play: lane-parallel Philox, then the serial state chain
-            uint32_t seq[NSEG];
+            // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
+            //      seq[seg] lane t = row in which step t was played.
+            uint32_t seq[NSEG], rwv[NSEG];
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 const int n = min(64, T - seg * 64);
@@ -179,81 +230,106 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                 const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
                 const uint32_t rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) |
                                     (__umulhi(x.w, (uint32_t)A) << 16);
+                rwv[seg] = rw;
                 uint32_t sq = 0;
                 for (int t = 0; t < n; t++) {
                     const uint32_t w = readlane_u(rw, t);
-                    uint32_t g0 = readlane_u(am0[0], s & 63), g1 = readlane_u(am1[0], s & 63);
-                    if (NRSEG > 1) {
-                        const uint32_t h0 = readlane_u(am0[NRSEG - 1], s & 63);
-                        const uint32_t h1 = readlane_u(am1[NRSEG - 1], s & 63);
-                        if (s >= 64) { g0 = h0; g1 = h1; }
+                    sq = (lane == t) ? (uint32_t)s : sq;
+                    if ((w & 3u) == 0u) {
+                        s = (int)read_row<NRSEG>(grow, s);           // both greedy: no LDS on the chain
+                    } else {
+                        const uint32_t a0 = (w & 1u) ? ((w >> 8) & 0xFFu) : read_row<NRSEG>(am0, s);
+                        const uint32_t a1 = (w & 2u) ? ((w >> 16) & 0xFFu) : read_row<NRSEG>(am1, s);
+                        s = __builtin_amdgcn_readfirstlane((int)lut_ns[a0 * (uint32_t)A + a1]);
                     }
-                    const uint32_t a0 = (w & 1u) ? ((w >> 8) & 0xFFu) : g0;
-                    const uint32_t a1 = (w & 2u) ? ((w >> 16) & 0xFFu) : g1;
-                    sq = (lane == t) ? ((uint32_t)s | (a0 << 8) | (a1 << 16)) : sq;
-                    last_idx = (int)(a0 * (uint32_t)A + a1);
-                    s = __builtin_amdgcn_readfirstlane((int)lut_ns[last_idx]);
                 }
                 seq[seg] = sq;
             }
             const int s_end = s;
 
-            // ---- (d) lane-parallel replay prologue (lane = step): rewards, old-value
-            //          snapshot (agents.py:67), log sums, visit counters (agents.py:76)
-            uint32_t pk[NSEG];
-            float re0[NSEG], re1[NSEG], t40[NSEG], t41[NSEG];
-            double lr0 = 0.0, lr1 = 0.0, la0 = 0.0, la1 = 0.0;
+            // ---- (d1) lane-parallel (lane = step): actions, old-value snapshot
+            //      (agents.py:67) for ALL steps before any TD write
+            uint32_t act[NSEG];            // a0 | a1<<8 | train_row<<16 | next_row<<24
+            v2u t4q[NSEG];                 // (1-alpha)*old_value, halves packed per 32 steps
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 const int tt = seg * 64 + lane;
                 const bool valid = tt < T;
-                const uint32_t word = seq[seg];
-                const int my_s = (tt == 0) ? st_first : (int)(word & 0xFFu);
-                const uint32_t a0 = (word >> 8) & 0xFFu, a1 = (word >> 16) & 0xFFu;
-                uint32_t nw = (uint32_t)__shfl_down((int)word, 1, 64);
-                if (seg + 1 < NSEG) { if (lane == 63) nw = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
-                const int ns = (tt + 1 < T) ? (int)(nw & 0xFFu) : s_end;
-                const int idx = valid ? (int)(a0 * (uint32_t)A + a1) : 0;
-                const double price = lut_price[idx];
-                const double r0d = __dmul_rn(price, lut_aq[valid ? a0 : 0]);
-                const double r1d = __dmul_rn(price, lut_aq[A + (valid ? a1 : 0)]);
-                re0[seg] = (float)r0d; re1[seg] = (float)r1d;
-                const int srow = valid ? my_s : 0;
-                const float ov0 = tab0[srow * A + (valid ? a0 : 0)];
-                const float ov1 = tab1[srow * A + (valid ? a1 : 0)];
-                t40[seg] = __fmul_rn(p0.one_minus_alpha_f, ov0);
-                t41[seg] = __fmul_rn(p1.one_minus_alpha_f, ov1);
-                pk[seg] = (uint32_t)srow | ((uint32_t)ns << 8) | (a0 << 16) | (a1 << 24);
+                const uint32_t my_s = seq[seg] & 0xFFu;
+                const uint32_t rw = rwv[seg];
+                // gather with ALL lanes active (a bpermute reads only from active lanes, and
+                // the source lane here is a table row, unrelated to this lane's step), then select
+                const uint32_t g0 = gather_row<NRSEG>(am0, my_s);
+                const uint32_t g1 = gather_row<NRSEG>(am1, my_s);
+                uint32_t a0 = (rw & 1u) ? ((rw >> 8) & 0xFFu) : g0;
+                uint32_t a1 = (rw & 2u) ? ((rw >> 16) & 0xFFu) : g1;
+                uint32_t nxt = (uint32_t)__shfl_down((int)seq[seg], 1, 64);
+                if (seg + 1 < NSEG) { if (lane == 63) nxt = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
+                const uint32_t ns = (tt + 1 < T) ? (nxt & 0xFFu) : (uint32_t)s_end;
+                uint32_t srow = (tt == 0) ? (uint32_t)st_first : my_s;
+                if (!valid) { a0 = 0; a1 = 0; srow = 0; }
+                const float ov0 = tab0[srow * A + a0];
+                const float ov1 = tab1[srow * A + a1];
+                t4q[seg] = pack_halves(__builtin_bit_cast(unsigned, __fmul_rn(p0.one_minus_alpha_f, ov0)),
+                                       __builtin_bit_cast(unsigned, __fmul_rn(p1.one_minus_alpha_f, ov1)));
+                act[seg] = a0 | (a1 << 8) | (srow << 16) | (ns << 24);
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            double lr0 = 0.0, lr1 = 0.0, la0 = 0.0, la1 = 0.0;
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                // ---- (d2) rewards, LDS write addresses, logs, visit counters of this segment
+                const int tt = seg * 64 + lane;
+                const bool valid = tt < T;
+                const uint32_t a0 = act[seg] & 0xFFu, a1 = (act[seg] >> 8) & 0xFFu;
+                const uint32_t srow = (act[seg] >> 16) & 0xFFu, ns = act[seg] >> 24;
+                const double price = lut_price[a0 * (uint32_t)A + a1];
+                const double r0d = __dmul_rn(price, lut_aq[a0]);
+                const double r1d = __dmul_rn(price, lut_aq[A + a1]);
+                if (seg == NSEG - 1) {
+                    const int ll = T - 1 - seg * 64;       // lane of the episode's last step
+                    last_price = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(price), ll),
+                                                  __builtin_amdgcn_readlane(__double2loint(price), ll));
+                }
+                const v2u req = pack_halves(__builtin_bit_cast(unsigned, (float)r0d),
+                                            __builtin_bit_cast(unsigned, (float)r1d));
+                const v2u woq = pack_halves(tab0_off + (srow * A + a0) * 4u, tab1_off + (srow * A + a1) * 4u);
+                const uint32_t nsoff = ns * (uint32_t)A * 4u;
                 if (valid) {
                     lr0 += __ddiv_rn(r0d, inv_T_den); lr1 += __ddiv_rn(r1d, inv_T_den);
                     la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
                     if (a.counter) {
-                        const int grow = srow < W ? lo + srow : (srow == W ? spill0 : spill1);
-                        int32_t* cb = a.counter + (int64_t)g * a.stride + grow * A;
+                        const int grow_ = (int)srow < W ? lo + (int)srow : ((int)srow == W ? spill0 : spill1);
+                        int32_t* cb = a.counter + (int64_t)g * a.stride + grow_ * A;
                         atomicAdd(cb + p0.table_off + a0, 1);
                         atomicAdd(cb + p1.table_off + a1, 1);
                     }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
 
-            // ---- (e) replay chain (agents.py:68-76): live next_max, sequential writes
+                // ---- (e) replay chain (agents.py:68-76): live next_max, sequential writes.
+                //      Per step: 3 bpermutes fetch this half's reward / old-value term /
+                //      write address, one ds_read of the next-state row, the half max,
+                //      4 float ops, one masked ds_write.
 #pragma unroll
-            for (int seg = 0; seg < NSEG; seg++) {
-                const int n = min(64, T - seg * 64);
-                for (int t = 0; t < n; t++) {
-                    const uint32_t w = readlane_u(pk[seg], t);
-                    const int stt = (int)(w & 0xFFu), nst = (int)((w >> 8) & 0xFFu);
-                    const int a0 = (int)((w >> 16) & 0xFFu), a1 = (int)(w >> 24);
-                    const float r0 = readlane_f(re0[seg], t), r1 = readlane_f(re1[seg], t);
-                    const float u0 = readlane_f(t40[seg], t), u1 = readlane_f(t41[seg], t);
-                    const float m = half_max_to_last_lane(tabh_col[nst * A]);
-                    const float nm0 = readlane_f(m, 31), nm1 = readlane_f(m, 63);
-                    const float v0 = __fadd_rn(u0, __fmul_rn(p0.alpha_f, __fadd_rn(r0, __fmul_rn(p0.gamma_f, nm0))));
-                    const float v1 = __fadd_rn(u1, __fmul_rn(p1.alpha_f, __fadd_rn(r1, __fmul_rn(p1.gamma_f, nm1))));
-                    if (lane == 0) tab0[stt * A + a0] = v0;
-                    if (lane == 32) tab1[stt * A + a1] = v1;
-                    __builtin_amdgcn_wave_barrier();
+                for (int k = 0; k < 2; k++) {
+                    const int nsub = min(32, T - seg * 64 - k * 32);
+                    const unsigned re_k = k ? req.y : req.x;
+                    const unsigned t4_k = k ? t4q[seg].y : t4q[seg].x;
+                    const unsigned wo_k = k ? woq.y : woq.x;
+                    for (int t = 0; t < nsub; t++) {
+                        const unsigned sel = sel_base + ((unsigned)t << 2);
+                        const float re = __builtin_bit_cast(float, bperm(sel, re_k));
+                        const float t4 = __builtin_bit_cast(float, bperm(sel, t4_k));
+                        const unsigned wo = bperm(sel, wo_k);
+                        const unsigned nso = readlane_u(nsoff, k * 32 + t);
+                        const float row_v = *reinterpret_cast<const float*>(
+                            reinterpret_cast<const unsigned char*>(tabh_col) + nso);
+                        const float nm = half_max_all_lanes(row_v);
+                        const float val = __fadd_rn(t4, __fmul_rn(alpha_h, __fadd_rn(re, __fmul_rn(gamma_h, nm))));
+                        if (writer) *reinterpret_cast<float*>(smem + wo) = val;
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
 
@@ -281,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                 q0[spill1 * A + lane] = tab0[(W + 1) * A + lane];
                 q1[spill1 * A + lane] = tab1[(W + 1) * A + lane];
             }
-            if (lane == 0 && last_idx >= 0) a.state[g] = lut_price[last_idx];
+            if (lane == 0 && a.n_episodes > 0) a.state[g] = last_price;
         }
         __builtin_amdgcn_wave_barrier();
     }
