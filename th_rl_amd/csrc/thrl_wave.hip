@@ -119,8 +119,11 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
     }
 }
 
+// LDS capacity allows 20 resident waves per CU for the headline window, i.e. 5 per
+// SIMD: keep the register allocation at <= 96 VGPRs there (NSEG <= 2).
 template <int NSEG, int NRSEG>
-__global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NSEG <= 2 ? 5 : 4)))
+k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
             //          during play: agents.py only writes it in train_net), and the
             //          greedy-greedy successor row of every row
-            uint32_t am0[NRSEG], am1[NRSEG], grow[NRSEG];
+            uint32_t am0[NRSEG], am1[NRSEG], am0A[NRSEG], grow[NRSEG];
 #pragma unroll
             for (int k = 0; k < NRSEG; k++) {
                 const int row = min(lane + 64 * k, W + 1);
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                     if (v0 > b0) { b0 = v0; i0 = j; }
                     if (v1 > b1) { b1 = v1; i1 = j; }
                 }
-                am0[k] = i0; am1[k] = i1;
+                am0[k] = i0; am1[k] = i1; am0A[k] = i0 * (uint32_t)A;
                 grow[k] = lut_ns[i0 * (uint32_t)A + i1];
             }
 
@@ -232,15 +235,34 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                                     (__umulhi(x.w, (uint32_t)A) << 16);
                 rwv[seg] = rw;
                 uint32_t sq = 0;
-                for (int t = 0; t < n; t++) {
-                    const uint32_t w = readlane_u(rw, t);
-                    sq = (lane == t) ? (uint32_t)s : sq;
-                    if ((w & 3u) == 0u) {
-                        s = (int)read_row<NRSEG>(grow, s);           // both greedy: no LDS on the chain
-                    } else {
-                        const uint32_t a0 = (w & 1u) ? ((w >> 8) & 0xFFu) : read_row<NRSEG>(am0, s);
-                        const uint32_t a1 = (w & 2u) ? ((w >> 16) & 0xFFu) : read_row<NRSEG>(am1, s);
-                        s = __builtin_amdgcn_readfirstlane((int)lut_ns[a0 * (uint32_t)A + a1]);
+                // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
+                // for every row r the next row if step t were played in r,
+                //   nsr_t[r] = LUT[a0][a1],  a_i = explore_i(t) ? choice_i(t) : argmax_i[r];
+                // it does not depend on the current state, so its LDS gathers overlap.
+                // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step.
+                for (int t0 = 0; t0 < n; t0 += 4) {
+                    uint32_t nsr[4][NRSEG];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t w = readlane_u(rw, min(t0 + j, 63));
+                        if ((w & 3u) == 0u) {
+#pragma unroll
+                            for (int k = 0; k < NRSEG; k++) nsr[j][k] = grow[k];
+                        } else {
+                            const uint32_t c0A = ((w >> 8) & 0xFFu) * (uint32_t)A, c1 = (w >> 16) & 0xFFu;
+#pragma unroll
+                            for (int k = 0; k < NRSEG; k++) {
+                                const uint32_t idx = ((w & 1u) ? c0A : am0A[k]) + ((w & 2u) ? c1 : am1[k]);
+                                nsr[j][k] = lut_ns[idx];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (t0 + j < n) {
+                            sq = (lane == t0 + j) ? (uint32_t)s : sq;
+                            s = (int)read_row<NRSEG>(nsr[j], s);
+                        }
                     }
                 }
                 seq[seg] = sq;
@@ -317,14 +339,17 @@ __global__ void __launch_bounds__(1024) k_wave_episodes(const WaveArgs a) {
                     const unsigned re_k = k ? req.y : req.x;
                     const unsigned t4_k = k ? t4q[seg].y : t4q[seg].x;
                     const unsigned wo_k = k ? woq.y : woq.x;
+                    // operands of step t+1 are fetched while step t's max chain runs
+                    unsigned re_n = bperm(sel_base, re_k), t4_n = bperm(sel_base, t4_k), wo_n = bperm(sel_base, wo_k);
                     for (int t = 0; t < nsub; t++) {
-                        const unsigned sel = sel_base + ((unsigned)t << 2);
-                        const float re = __builtin_bit_cast(float, bperm(sel, re_k));
-                        const float t4 = __builtin_bit_cast(float, bperm(sel, t4_k));
-                        const unsigned wo = bperm(sel, wo_k);
+                        const float re = __builtin_bit_cast(float, re_n);
+                        const float t4 = __builtin_bit_cast(float, t4_n);
+                        const unsigned wo = wo_n;
                         const unsigned nso = readlane_u(nsoff, k * 32 + t);
                         const float row_v = *reinterpret_cast<const float*>(
                             reinterpret_cast<const unsigned char*>(tabh_col) + nso);
+                        const unsigned sel = sel_base + ((unsigned)min(t + 1, 31) << 2);
+                        re_n = bperm(sel, re_k); t4_n = bperm(sel, t4_k); wo_n = bperm(sel, wo_k);
                         const float nm = half_max_all_lanes(row_v);
                         const float val = __fadd_rn(t4, __fmul_rn(alpha_h, __fadd_rn(re, __fmul_rn(gamma_h, nm))));
                         if (writer) *reinterpret_cast<float*>(smem + wo) = val;
