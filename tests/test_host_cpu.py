@@ -1,0 +1,224 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, the
+host logic of the ABI (no GPU needed), the Python mirror of the reference API, and
+the world_size-2 sharding path over gloo."""
+import ctypes
+import json
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CFG_AGENT = dict(name="QTable", gamma=0.95, actions=21, states=100, alpha=0.1, eps_end=0.001,
+                 epsilon=0.5, eps_step=0.9995, action_range=[0.2, 0.4])
+CFG_ENV = dict(name="NoisyPriceState", noise_prob=0, a=10, b=1, nplayers=2, max_steps=100)
+CFG = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV),
+       "training": {"print_freq": 500, "epochs": 20}}
+# the reference's example_config.json content (QTable vs Reinforce), restated as data
+EXAMPLE = {"agents": [dict(CFG_AGENT),
+                      {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}],
+           "environment": dict(CFG_ENV), "training": {"print_freq": 500, "epochs": 20000}}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from th_rl_amd import build, _lib
+    build.build()          # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from th_rl_amd import _lib
+    header = open(os.path.join(ROOT, "include", "thrl.h")).read()
+    declared = sorted(set(re.findall(r"\b(thrl_[a-z0-9_]+)\s*\(", header)))
+    assert declared and set(declared) == set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.thrl_version() == 1
+
+
+def test_struct_layout_matches_header(lib):
+    """ctypes mirrors of thrl_cfg / thrl_buffers / thrl_run have the C sizes."""
+    import subprocess, tempfile
+    from th_rl_amd import _lib
+    src = '#include <stdio.h>\n#include "thrl.h"\nint main(){printf("%zu %zu %zu\\n",sizeof(thrl_cfg),sizeof(thrl_buffers),sizeof(thrl_run));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
+    assert sizes == [ctypes.sizeof(_lib.Cfg), ctypes.sizeof(_lib.Buffers), ctypes.sizeof(_lib.Run)]
+
+
+def test_host_logic_layout_and_kernel_selection(lib):
+    from th_rl_amd import _lib
+    cfg, eps = _lib.cfg_from_config(CFG, 1 << 20, 0)
+    assert eps == [0.5, 0.5]
+    assert lib.thrl_table_stride(ctypes.byref(cfg)) == 2 * 101 * 21
+    assert lib.thrl_table_offset(ctypes.byref(cfg), 1) == 101 * 21
+    assert lib.thrl_workspace_bytes(ctypes.byref(cfg)) > 0
+    assert lib.thrl_select_kernel(ctypes.byref(cfg), 0) == _lib.KERNEL_WAVE
+    assert lib.thrl_select_kernel(ctypes.byref(cfg), 1) == _lib.KERNEL_GENERIC      # injected draws
+    # replay memory holds at most T=100 transitions/agent here: 2*100*G entries * (3*2 + 2*8) bytes
+    assert lib.thrl_replay_mem_bytes(ctypes.byref(cfg)) == (1 << 20) * 2 * 100 * 22
+    for mod, why in [(dict(q=1), "float32"), (dict(noise=0.05), "noise"), (dict(T=30), "min_memory"),
+                     (dict(nag=3), "2 agents"), (dict(cap=64), "capacity")]:
+        c = json.loads(json.dumps(CFG))
+        if "noise" in mod: c["environment"]["noise_prob"] = mod["noise"]
+        if "T" in mod: c["environment"]["max_steps"] = mod["T"]
+        if "cap" in mod: c["agents"][0]["capacity"] = mod["cap"]
+        if "nag" in mod: c["agents"].append(dict(CFG_AGENT)); c["environment"]["nplayers"] = 3
+        cfg2, _ = _lib.cfg_from_config(c, 64, mod.get("q", 0))
+        assert lib.thrl_select_kernel(ctypes.byref(cfg2), 0) == _lib.KERNEL_GENERIC, mod
+        assert why in lib.thrl_last_error().decode(), (mod, lib.thrl_last_error())
+
+
+def test_error_codes_never_throw(lib):
+    from th_rl_amd import _lib
+    cfg, _ = _lib.cfg_from_config(CFG, 4, 0)
+    cfg.n_agents = 0
+    assert lib.thrl_select_kernel(ctypes.byref(cfg), 0) == -1          # THRL_ERR_BAD_CONFIG
+    assert b"n_agents" in lib.thrl_last_error()
+    cfg, _ = _lib.cfg_from_config(CFG, 4, 0)
+    cfg.n_actions[1] = 1
+    assert lib.thrl_replay_mem_bytes(ctypes.byref(cfg)) == 0
+    cfg, _ = _lib.cfg_from_config(CFG, 4, 0)
+    # NULL buffers are rejected before anything touches the device
+    assert lib.thrl_qtable_init(ctypes.byref(cfg), None, None, None, 0, 0, None) == -2
+    run = _lib.Run(); bufs = _lib.Buffers()
+    assert lib.thrl_qtable_episodes(ctypes.byref(cfg), ctypes.byref(bufs), ctypes.byref(run), None) == -2
+    assert lib.thrl_play_greedy(ctypes.byref(cfg), None, None, 1, 0, 0, None, None, None) == -2
+    assert lib.thrl_op_env_step(ctypes.byref(cfg), None, None, None, None, None, None) == -2
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from th_rl_amd.batched import GameBatch
+    from th_rl_amd._lib import ThrlError
+    with pytest.raises(ThrlError, match="no GPU|no CPU fallback"):
+        GameBatch(CFG, n_games=4)
+    from th_rl_amd.agents import QTable
+    from th_rl_amd.environments import NoisyPriceState
+    with pytest.raises(ThrlError):
+        QTable(**CFG_AGENT).get_action(np.array([3.0]))
+    with pytest.raises(ThrlError):
+        NoisyPriceState(**CFG_ENV).step([0.3, 0.3])
+
+
+def test_create_game_reference_schema(tmp_path):
+    from th_rl_amd import trainer
+    from th_rl_amd.agents import QTable, Reinforce
+    from th_rl_amd.environments import NoisyPriceState, PricingGame
+    p = tmp_path / "example_config.json"
+    p.write_text(json.dumps(EXAMPLE, indent=3))
+    np.random.seed(0)
+    config, agents, env = trainer.create_game(str(p))
+    assert config == EXAMPLE
+    assert isinstance(agents[0], QTable) and isinstance(agents[1], Reinforce)
+    assert isinstance(env, NoisyPriceState) and PricingGame is NoisyPriceState
+    assert trainer.train is trainer.train_one
+    q = agents[0]
+    assert q.table.shape == (101, 21) and q.table.dtype == np.float64
+    assert abs(q.table.mean() - 250.0) < 0.1 and not q.counter.any()
+    assert (q.states, q.actions, q.max_state, q.min_memory, q.epsilon) == (100, 21, 10, 100, 0.5)
+    assert list(q.action_space) == list(range(21)) and len(q.memory) == 0
+    assert 0 <= env.state < 10 and env.max_steps == 100 and env.episode == 0
+    nash, cartel = env.get_optimal()
+    assert abs(nash - 200 / 9) < 1e-12 and cartel == 25.0
+    assert sum(x.numel() for x in agents[1].parameters()) == 5909
+    bad = json.loads(json.dumps(EXAMPLE)); bad["environment"]["nplayers"] = 3
+    p.write_text(json.dumps(bad))
+    with pytest.raises(AssertionError, match="Bad config"):
+        trainer.create_game(str(p))
+
+
+def test_replay_buffer_semantics():
+    """deque(maxlen) append / ordered replay / empty / sample (buffers.py:6-41)."""
+    from collections import namedtuple
+    import torch
+    from th_rl_amd.buffers import ReplayBuffer
+    Exp = namedtuple("Experience", ["state", "action", "reward", "done", "new_state"])
+    rb = ReplayBuffer(5, Exp)
+    for k in range(7):
+        rb.append(np.array([float(k)]), k, 0.5 * k, True, np.array([k + 1.0]))
+    assert len(rb) == 5
+    st, ac, rw, nd, ns = rb.replay()
+    assert list(ac) == [2, 3, 4, 5, 6] and list(rw) == [1.0, 1.5, 2.0, 2.5, 3.0]
+    st, ac, rw, nd, ns = rb.replay(replay_size=2)
+    assert list(ac) == [5, 6]
+    cast = [torch.float, torch.int64, torch.float, torch.float, torch.float]
+    t = list(rb.replay(cast))
+    assert t[0].shape == (5, 1) and t[1].dtype == torch.int64 and t[1].tolist() == [2, 3, 4, 5, 6]
+    np.random.seed(1)
+    _, ac, _, _, _ = rb.sample(3)
+    assert len(set(ac)) == 3 and set(ac) <= {2, 3, 4, 5, 6}
+    rb.empty()
+    assert len(rb) == 0 and rb.buffer.maxlen == 5
+
+
+def test_qtable_save_load_format(tmp_path):
+    from th_rl_amd.agents import QTable
+    np.random.seed(3)
+    q = QTable(**CFG_AGENT)
+    q.counter[3, 4] = 7
+    q.save(str(tmp_path / "0"))
+    assert sorted(os.listdir(tmp_path)) == ["0.npy", "0_counter.npy"]
+    assert os.path.getsize(tmp_path / "0.npy") == 17096
+    r = QTable(**CFG_AGENT)
+    r.load(str(tmp_path / "0"))
+    assert np.array_equal(r.table, q.table) and r.counter[3, 4] == 7 and r.table.dtype == np.float64
+
+
+def test_shard_range_partitions():
+    from th_rl_amd.sharding import shard_range
+    for total, world in [(1 << 23, 8), (10, 3), (7, 8), (1 << 20, 1)]:
+        blocks = [shard_range(total, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and sum(n for _, n in blocks) == total
+        for (o0, n0), (o1, _) in zip(blocks, blocks[1:]):
+            assert o0 + n0 == o1
+    with pytest.raises(ValueError):
+        shard_range(8, 8, 8)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _shard_worker(rank, world, port, total, E, q):
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from th_rl_amd.sharding import shard_range, aggregate_logs
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    off, n = shard_range(total, rank, world)
+    cfg, eps = O.cfg_from_config(CFG, n, 0)
+    tab, cnt, st = O.init(cfg, seed=7, game_offset=off)
+    out = O.episodes(cfg, tab, cnt, st, eps, O.Memory(cfg), E, seed=7, game_offset=off)
+    merged = aggregate_logs(out["reward_log"], n)
+    dist.barrier()
+    if rank == 0:
+        q.put((merged, tab.sum()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_seed_sharding_over_gloo():
+    """world_size 2 on CPU: each rank runs its block of games (the oracle stands in for
+    the device kernel), logs are merged with a weighted mean; equals the 1-rank run."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    total, E = 11, 3            # uneven split: 6 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, total, E, q)) for r in range(2)]
+    [p.start() for p in procs]
+    merged, _ = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    cfg, eps = O.cfg_from_config(CFG, total, 0)
+    tab, cnt, st = O.init(cfg, seed=7)
+    out = O.episodes(cfg, tab, cnt, st, eps, O.Memory(cfg), E, seed=7)
+    np.testing.assert_allclose(merged, out["reward_log"], rtol=1e-13)

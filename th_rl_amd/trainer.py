@@ -1,0 +1,125 @@
+"""create_game / train_one -- the reference's trainer entry points (th_rl/trainer.py)
+with the same signatures, config schema and output files, driving the GPU.
+
+train_one runs the whole episode loop on the device through GameBatch (fused HIP
+kernels).  The JSON schema is the reference's; the optional extra keys in the
+"training" block select the batched mode and default to reference behaviour:
+
+    "training": {"epochs": .., "print_freq": ..,
+                 "n_games": 1,        # games trained in lockstep (independent replicas)
+                 "seed": null,        # Philox seed (null: drawn from numpy's global RNG)
+                 "dtype": null,       # "float64" | "float32" (default f64 for 1 game, f32 otherwise)
+                 "device": "cuda:0", "game_offset": 0, "kernel": "auto"}
+
+n_games == 1: tables come from the constructed agents (numpy's global RNG, exactly where
+the reference draws them) and the run is float64.  n_games > 1: every game's tables and
+initial state come from Philox keyed by (seed, global game id).  Output files are the
+reference's four artefacts for game 0 (`<i>.npy`, `<i>_counter.npy`, `config.json`,
+`log.csv` -- the log is the MEAN over games), plus `batch.pt` with all games when
+n_games > 1.  There is no CPU fallback: without the HIP library or a GPU this raises.
+"""
+import json
+import os
+import time
+
+import numpy
+import pandas
+
+from th_rl_amd.environments import *  # noqa: F401,F403  (class names are eval'd, as in the reference)
+from th_rl_amd.agents import *        # noqa: F401,F403
+from th_rl_amd import _lib
+from th_rl_amd.batched import GameBatch
+
+
+def create_game(configpath):
+    """JSON -> (config, agents, environment), constructed by name like the reference."""
+    config = json.load(open(configpath))
+    agents = [eval(agent["name"])(**agent) for agent in config["agents"]]
+    assert (
+        len(agents) == config["environment"]["nplayers"]
+    ), "Bad config. Check number of agents."
+    environment = eval(config["environment"]["name"])(**config["environment"])
+    return config, agents, environment
+
+
+def _progress_line(print_eps, eps, elapsed, e, rew, act, names):
+    head = ""
+    if print_eps:
+        head = "eps:{} | ".format(numpy.round(numpy.array(eps) * 1000) / 1000)
+    return head + "time:{:2.2f} | episode:{:3d} | reward:{} | agents:{} | actions:{}".format(
+        elapsed, e, numpy.round(100 * rew) / 100, ",".join(names), numpy.round(100 * act) / 100)
+
+
+def train_one(exp_path, configpath, loadonly=False, print_eps=False):
+    if not os.path.exists(exp_path):
+        os.mkdir(os.path.join(exp_path))
+
+    config, agents, environment = create_game(configpath)
+    if not all(isinstance(a, QTable) for a in agents) or not isinstance(environment, NoisyPriceState):
+        raise NotImplementedError(
+            "train_one: the device path trains QTable agents on NoisyPriceState; "
+            "neural agents are outside this round's scope (SURVEY.md section 8f)")
+
+    training = config.get("training", {})
+    epochs = training.get("epochs", 0)
+    print_freq = training.get("print_freq", 500)
+    n_games = int(training.get("n_games", 1))
+    seed = training.get("seed", None)
+    if seed is None:
+        seed = int(numpy.random.randint(0, 2 ** 31 - 1))
+    dtype = training.get("dtype", None) or ("float64" if n_games == 1 else "float32")
+    names = [a["name"] for a in config["agents"]]
+
+    batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
+                      seed=seed, game_offset=int(training.get("game_offset", 0)),
+                      kernel=training.get("kernel", "auto"))
+    if n_games == 1:
+        state = environment.reset()                     # drawn once, as trainer.py:45
+        batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
+    else:
+        batch.init_tables()
+
+    rewards_log = numpy.zeros((epochs, len(agents)))
+    actions_log = numpy.zeros((epochs, len(agents)))
+
+    t = time.time()
+    done = 0
+    chunk = max(1, int(print_freq)) if print_freq else epochs
+    while done < epochs:
+        n = min(chunk - (done % chunk), epochs - done)
+        out = batch.run(n)
+        rewards_log[done:done + n] = out["reward_log"]
+        actions_log[done:done + n] = out["action_log"]
+        done += n
+        if print_freq and not done % print_freq:
+            rew = numpy.mean(rewards_log[done - print_freq:done, :], axis=0)
+            act = numpy.mean(actions_log[done - print_freq:done, :], axis=0)
+            print(_progress_line(print_eps, batch.eps, time.time() - t, done - 1, rew, act, names))
+            t = time.time()
+
+    # Store result: the reference's artefacts, from game 0
+    for i, a in enumerate(agents):
+        a.table = batch.table(0, i)
+        a.counter = batch.counter_of(0, i)
+        a.epsilon = batch.eps[i]
+        a.save(os.path.join(exp_path, str(i)))
+    environment.state = numpy.float64(batch.states_numpy()[0])
+
+    with open(os.path.join(exp_path, "config.json"), "w") as f:
+        json.dump(config, f, indent=3)
+
+    rpd = pandas.DataFrame(data=rewards_log, columns=numpy.arange(len(agents)))
+    apd = pandas.DataFrame(data=actions_log, columns=numpy.arange(len(agents)))
+    log = pandas.concat([rpd, apd], axis=1, keys=["rewards", "actions"])
+    log.to_csv(os.path.join(exp_path, "log.csv"), index=None)
+
+    if n_games > 1:
+        import torch
+        torch.save({"q": batch.q.cpu(), "counter": None if batch.counter is None else batch.counter.cpu(),
+                    "state": batch.state.cpu(), "eps": list(batch.eps), "episode": batch.episode,
+                    "seed": seed, "game_offset": batch.game_offset, "offsets": batch.offsets,
+                    "shapes": batch.shapes}, os.path.join(exp_path, "batch.pt"))
+
+
+# BASELINE.json's north_star names the entry point "trainer.train()"; the reference's is train_one.
+train = train_one
