@@ -63,6 +63,14 @@ __device__ __forceinline__ v2u pack_halves(unsigned a, unsigned b) {
     return __builtin_amdgcn_permlane32_swap(a, b, false, false);
 }
 
+// LDS access by 32-bit LDS address (address space 3): no generic-pointer arithmetic
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ float lds_load_f32(unsigned addr) { return *(const lds_f32*)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_store_f32(unsigned addr, float v) { *(lds_f32*)(uintptr_t)addr = v; }
+
 __device__ __forceinline__ unsigned bperm(unsigned byte_sel, unsigned v) {
     return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_sel, (int)v);
 }
@@ -146,8 +154,9 @@ k_wave_episodes(const WaveArgs a) {
     const int half = lane >> 5;
     const int col = min(lane & 31, A - 1);
     float* tabh_col = (half ? tab1 : tab0) + col;
-    const unsigned tab0_off = (unsigned)(reinterpret_cast<unsigned char*>(tab0) - smem);
-    const unsigned tab1_off = (unsigned)(reinterpret_cast<unsigned char*>(tab1) - smem);
+    const unsigned tab0_off = lds_addr(tab0);        // absolute LDS byte addresses
+    const unsigned tab1_off = lds_addr(tab1);
+    const unsigned tabh_col_lds = lds_addr(tabh_col);
     const unsigned sel_base = (unsigned)(lane & 32) << 2;      // bpermute byte index of this half's lane 0
     const bool writer = (lane & 31) == 0;
 
@@ -335,25 +344,40 @@ k_wave_episodes(const WaveArgs a) {
                 //      4 float ops, one masked ds_write.
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const int nsub = min(32, T - seg * 64 - k * 32);
+                    const int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
                     const unsigned re_k = k ? req.y : req.x;
                     const unsigned t4_k = k ? t4q[seg].y : t4q[seg].x;
                     const unsigned wo_k = k ? woq.y : woq.x;
-                    // operands of step t+1 are fetched while step t's max chain runs
-                    unsigned re_n = bperm(sel_base, re_k), t4_n = bperm(sel_base, t4_k), wo_n = bperm(sel_base, wo_k);
-                    for (int t = 0; t < nsub; t++) {
-                        const float re = __builtin_bit_cast(float, re_n);
-                        const float t4 = __builtin_bit_cast(float, t4_n);
-                        const unsigned wo = wo_n;
-                        const unsigned nso = readlane_u(nsoff, k * 32 + t);
-                        const float row_v = *reinterpret_cast<const float*>(
-                            reinterpret_cast<const unsigned char*>(tabh_col) + nso);
-                        const unsigned sel = sel_base + ((unsigned)min(t + 1, 31) << 2);
-                        re_n = bperm(sel, re_k); t4_n = bperm(sel, t4_k); wo_n = bperm(sel, wo_k);
-                        const float nm = half_max_all_lanes(row_v);
-                        const float val = __fadd_rn(t4, __fmul_rn(alpha_h, __fadd_rn(re, __fmul_rn(gamma_h, nm))));
-                        if (writer) *reinterpret_cast<float*>(smem + wo) = val;
-                        __builtin_amdgcn_wave_barrier();
+                    // Operands of step t+1 are fetched while step t's max chain runs: the row
+                    // read is issued FIRST (LDS returns in order, so the wait before the max is
+                    // lgkmcnt(3), not 0).  Two steps per iteration so no register rotation.
+                    unsigned sel = sel_base;
+                    unsigned reA = bperm(sel, re_k), t4A = bperm(sel, t4_k), woA = bperm(sel, wo_k);
+                    unsigned reB = 0, t4B = 0, woB = 0;
+                    const int tb = k * 32;
+                    for (int t = 0; t < nsub; t += 2) {
+                        {
+                            const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t));
+                            __builtin_amdgcn_sched_barrier(0);
+                            sel += 4u;
+                            reB = bperm(sel, re_k); t4B = bperm(sel, t4_k); woB = bperm(sel, wo_k);
+                            const float nm = half_max_all_lanes(row_v);
+                            const float val = __fadd_rn(__builtin_bit_cast(float, t4A),
+                                __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reA), __fmul_rn(gamma_h, nm))));
+                            if (writer) lds_store_f32(woA, val);
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (t + 1 < nsub) {
+                            const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t + 1));
+                            __builtin_amdgcn_sched_barrier(0);
+                            sel += 4u;
+                            reA = bperm(sel, re_k); t4A = bperm(sel, t4_k); woA = bperm(sel, wo_k);
+                            const float nm = half_max_all_lanes(row_v);
+                            const float val = __fadd_rn(__builtin_bit_cast(float, t4B),
+                                __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reB), __fmul_rn(gamma_h, nm))));
+                            if (writer) lds_store_f32(woB, val);
+                            __builtin_amdgcn_wave_barrier();
+                        }
                     }
                 }
             }
@@ -389,17 +413,28 @@ k_wave_episodes(const WaveArgs a) {
     a.partial[(size_t)wave_gid * 64 + lane] = acc;
 }
 
-// fixed-order reduction of the per-wave partials -> mean logs [E][2]
-__global__ void __launch_bounds__(64) k_wave_reduce(const double* partial, int total_waves, int n_episodes,
-                                                    double G, double* reward_log, double* action_log) {
-    const int lane = threadIdx.x;
-    const int e = lane >> 2, k = lane & 3;
+// fixed-order reduction of the per-wave partials -> mean logs [E][2].
+// One block per accumulator slot j = e*4+k; thread i sums waves i, i+256, ... in order,
+// then a fixed-shape LDS tree: the result is deterministic for a given launch geometry.
+__global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int total_waves, int n_episodes,
+                                                     double G, double* reward_log, double* action_log) {
+    __shared__ double red[256];
+    const int j = blockIdx.x;
+    const int e = j >> 2, k = j & 3;
     if (e >= n_episodes) return;
     double s = 0.0;
-    for (int w = 0; w < total_waves; w++) s += partial[(size_t)w * 64 + lane];
-    s = __ddiv_rn(s, G);
-    if (k < 2) { if (reward_log) reward_log[e * 2 + k] = s; }
-    else { if (action_log) action_log[e * 2 + (k - 2)] = s; }
+    for (int w = threadIdx.x; w < total_waves; w += 256) s += partial[(size_t)w * 64 + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double m = __ddiv_rn(red[0], G);
+        if (k < 2) { if (reward_log) reward_log[e * 2 + k] = m; }
+        else { if (action_log) action_log[e * 2 + (k - 2)] = m; }
+    }
 }
 
 template <int NSEG, int NRSEG>
@@ -437,7 +472,7 @@ int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t 
 
 int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,
                        double* action_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_wave_reduce, dim3(1), dim3(64), 0, s, partial, total_waves, n_episodes, (double)G,
+    hipLaunchKernelGGL(k_wave_reduce, dim3(64), dim3(256), 0, s, partial, total_waves, n_episodes, (double)G,
                        reward_log, action_log);
     return (int)hipGetLastError();
 }
