@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=10, help="episodes per kernel launch (<=16)")
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="diagnostic only: run without QTable.counter (NOT the reported workload)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -104,7 +106,7 @@ def main():
     G = args.games
     chunk = max(1, min(16, args.chunk))
     gb = GameBatch(CFG, n_games=G, device=dev, dtype="float32", kernel=args.kernel, seed=0,
-                   game_offset=rank * G).init_tables()
+                   game_offset=rank * G, counters=not args.no_counters).init_tables()
 
     def run_steps(n, events=None):
         done = 0
@@ -167,7 +169,7 @@ def main():
                                    "parallel NoisyPriceState games per GPU, T=100, fused step+TD kernel"
                                    % G,
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
-                       "counters": True, "parallelism": "seed-sharded x%d, no collective" % n_gpus},
+                       "counters": not args.no_counters, "parallelism": "seed-sharded x%d, no collective" % n_gpus},
             "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

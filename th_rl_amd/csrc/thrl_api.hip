@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "thrl_kernels.h"
@@ -168,19 +169,26 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     p.win_rows = hi - lo + 1;
     if (p.win_rows + 2 > 128) NO("reachable row window > 126 rows");
     const WaveLut L = wave_lut_layout(A);
-    p.lut_bytes = L.bytes;
+    p.lut_bytes = L.lds_bytes;          // LDS-staged part of the LUT image
     p.game_lds_bytes = 2 * (p.win_rows + 2) * A * 4;
     // choose waves/block to maximise resident waves per CU (LDS-bound), block LDS <= 64 KiB
     int best_w = 0, best_total = 0, best_b = 0;
-    for (int w = 1; w <= 16; w++) {
-        const int lds = p.lut_bytes + w * p.game_lds_bytes;
-        if (lds > 65536) break;
-        int b = 163840 / (((lds + 511) / 512) * 512);
-        if (b * w > 32) b = 32 / w;
-        if (b < 1) continue;
-        const int total = b * w;
-        if (total > best_total || (total == best_total && w < best_w)) { best_total = total; best_w = w; best_b = b; }
-    }
+    int cap_waves = 32;                                   // tuning/diagnostic knob
+    if (const char* e = getenv("THRL_WAVE_MAX_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) cap_waves = v; }
+    // A block's waves are dealt to the CU's 4 SIMDs in turn, and every wave has the same
+    // amount of work, so blocks of 4k waves keep the SIMDs evenly loaded (5-wave blocks
+    // measured 21% slower at MORE resident waves).  Fall back to any size if none fits.
+    for (int pass = 0; pass < 2 && best_w == 0; pass++)
+        for (int w = 1; w <= 16; w++) {
+            if (pass == 0 && (w & 3)) continue;
+            const int lds = p.lut_bytes + w * p.game_lds_bytes;
+            if (lds > 65536) break;
+            int b = 163840 / (((lds + 511) / 512) * 512);
+            if (b * w > cap_waves) b = cap_waves / w;
+            if (b < 1) continue;
+            const int total = b * w;
+            if (total > best_total || (total == best_total && w < best_w)) { best_total = total; best_w = w; best_b = b; }
+        }
     if (best_w == 0) NO("table window does not fit LDS");
     p.waves_per_block = best_w;
     p.blocks_per_cu = best_b;
@@ -306,7 +314,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     if (!b->workspace || b->workspace_bytes < thrl_workspace_bytes(c))
         return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes,
                     thrl_workspace_bytes(c));
-    if (p.lut_bytes > (int)kLutRegion) return fail(THRL_ERR_UNSUPPORTED, "LUT image too large");
+    if (wave_lut_layout(c->n_actions[0]).bytes > (int)kLutRegion) return fail(THRL_ERR_UNSUPPORTED, "LUT image too large");
     WaveArgs a;
     memset(&a, 0, sizeof(a));
     a.G = c->n_games; a.T = c->max_steps; a.A = c->n_actions[0]; a.rows = c->n_states[0] + 1;

@@ -145,7 +145,7 @@ k_wave_episodes(const WaveArgs a) {
     }
     __syncthreads();
     const unsigned char* lut_ns = smem + L.ns_off;
-    const double* lut_price = reinterpret_cast<const double*>(smem + L.price_off);
+    const double* __restrict__ lut_price = reinterpret_cast<const double*>(a.lut_ns + L.price_off);   // HBM/L2
     const double* lut_aq = reinterpret_cast<const double*>(smem + L.aq_off);
     const double* lut_sct = reinterpret_cast<const double*>(smem + L.sct_off);
 

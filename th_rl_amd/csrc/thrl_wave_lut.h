@@ -7,19 +7,22 @@ namespace thrl {
 
 struct WaveLut {
     int ns_off;     // uint8  [A*A]  window-local next-state row per action pair (a0*A+a1)
-    int price_off;  // double [A*A]  price (= next env state) per action pair
     int aq_off;     // double [2][A] (a/b)*scale_i(k): quantity of agent i at action k
     int sct_off;    // double [2][A] scale_i(k)/T: per-step contribution to actions_log
+    int lds_bytes;  // the part above is staged in LDS (the ns LUT is on the serial chain)
+    int price_off;  // double [A*A]  price (= next env state) per action pair; read from the
+                    //               HBM image (L2-resident, 3.5 KB) by the lane-parallel prologue
     int bytes;      // total, multiple of 16
 };
 
 __host__ __device__ inline WaveLut wave_lut_layout(int A) {
     WaveLut l;
     l.ns_off = 0;
-    l.price_off = (A * A + 15) & ~15;
-    l.aq_off = l.price_off + 8 * A * A;
+    l.aq_off = (A * A + 15) & ~15;
     l.sct_off = l.aq_off + 16 * A;
-    l.bytes = (l.sct_off + 16 * A + 15) & ~15;
+    l.lds_bytes = (l.sct_off + 16 * A + 15) & ~15;
+    l.price_off = l.lds_bytes;
+    l.bytes = (l.price_off + 8 * A * A + 15) & ~15;
     return l;
 }
 
