@@ -100,7 +100,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU; the modulo only matters when rehearsing N ranks on a box with fewer GPUs
+    dev = torch.device("cuda", (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     G = args.games
