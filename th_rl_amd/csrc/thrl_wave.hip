@@ -29,12 +29,13 @@ namespace thrl {
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
-// max over each 32-lane half, result in EVERY lane of the half.
-// 4 single-instruction DPP max steps give each 16-lane row its max; the two rows of
-// a half are then exchanged with v_permlane16_swap (gfx950) and combined.
-// The s_nop 1 before each DPP op are the 2 wait states a DPP read of a
-// just-written VGPR needs (hipcc does not look inside asm statements).
-__device__ __forceinline__ float half_max_all_lanes(float v) {
+// max over each 32-lane half; the result is valid in the UPPER 16-lane row of each half
+// (lanes 16-31 and 48-63), which is where the replay loop's writer lanes (16, 48) sit.
+// Four single-instruction DPP max steps give every lane its 16-lane row max; row_bcast:15
+// then folds row 0 into row 1 and row 2 into row 3 (row_mask 0xA).
+// The s_nop 1 before each DPP op are the 2 wait states a DPP read of a just-written
+// VGPR needs (hipcc does not look inside asm statements).
+__device__ __forceinline__ float half_max_upper_row(float v) {
     asm("s_nop 1\n\t"
         "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
@@ -43,18 +44,11 @@ __device__ __forceinline__ float half_max_all_lanes(float v) {
         "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0"
         : "+v"(v));
-    const unsigned vi = __builtin_bit_cast(unsigned, v);
-    unsigned vj = vi;
-    asm("" : "+v"(vj));      // opaque copy: the swap needs two distinct registers
-    const v2u r = __builtin_amdgcn_permlane16_swap(vi, vj, false, false);
-    // (copy the elements out first: __builtin_bit_cast on r.x / r.y directly resolves
-    //  both to element 0 with this compiler)
-    const unsigned rx = r.x, ry = r.y;
-    float m;
-    asm("s_nop 0\n\tv_max_f32 %0, %1, %2" : "=v"(m) : "v"(__builtin_bit_cast(float, rx)), "v"(__builtin_bit_cast(float, ry)));
-    return m;
+    return v;
 }
 
 // lanes<32 of the result: lanes 0-31 of a ; lanes>=32: lanes 0-31 of b   (.x)
@@ -158,7 +152,7 @@ k_wave_episodes(const WaveArgs a) {
     const unsigned tab1_off = lds_addr(tab1);
     const unsigned tabh_col_lds = lds_addr(tabh_col);
     const unsigned sel_base = (unsigned)(lane & 32) << 2;      // bpermute byte index of this half's lane 0
-    const bool writer = (lane & 31) == 0;
+    const bool writer = (lane & 31) == 16;          // first lane of the row that holds the half max
 
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
@@ -328,7 +322,7 @@ k_wave_episodes(const WaveArgs a) {
                 const v2u woq = pack_halves(tab0_off + (srow * A + a0) * 4u, tab1_off + (srow * A + a1) * 4u);
                 const uint32_t nsoff = ns * (uint32_t)A * 4u;
                 if (valid) {
-                    lr0 += __ddiv_rn(r0d, inv_T_den); lr1 += __ddiv_rn(r1d, inv_T_den);
+                    lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
                     la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
                     if (a.counter) {
                         const int grow_ = (int)srow < W ? lo + (int)srow : ((int)srow == W ? spill0 : spill1);
@@ -361,7 +355,7 @@ k_wave_episodes(const WaveArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
                             reB = bperm(sel, re_k); t4B = bperm(sel, t4_k); woB = bperm(sel, wo_k);
-                            const float nm = half_max_all_lanes(row_v);
+                            const float nm = half_max_upper_row(row_v);
                             const float val = __fadd_rn(__builtin_bit_cast(float, t4A),
                                 __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reA), __fmul_rn(gamma_h, nm))));
                             if (writer) lds_store_f32(woA, val);
@@ -372,7 +366,7 @@ k_wave_episodes(const WaveArgs a) {
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
                             reA = bperm(sel, re_k); t4A = bperm(sel, t4_k); woA = bperm(sel, wo_k);
-                            const float nm = half_max_all_lanes(row_v);
+                            const float nm = half_max_upper_row(row_v);
                             const float val = __fadd_rn(__builtin_bit_cast(float, t4B),
                                 __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reB), __fmul_rn(gamma_h, nm))));
                             if (writer) lds_store_f32(woB, val);
@@ -384,7 +378,7 @@ k_wave_episodes(const WaveArgs a) {
 
             // ---- (f) per-episode log sums of this game into the wave accumulator
             {
-                const double w0 = wave_sum64(lr0), w1 = wave_sum64(lr1);
+                const double w0 = __ddiv_rn(wave_sum64(lr0), inv_T_den), w1 = __ddiv_rn(wave_sum64(lr1), inv_T_den);
                 const double w2 = wave_sum64(la0), w3 = wave_sum64(la1);
                 const int k = lane & 3;
                 const double v = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
