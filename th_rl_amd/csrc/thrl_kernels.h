@@ -56,6 +56,7 @@ struct WaveArgs {
     double* state;
     const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
     double* partial;                // device [total_waves][E][4] per-wave log sums
+    uint32_t* tlog;                 // device [total_waves][16 episodes][NSEG][64] packed transitions
     uint64_t seed, game_offset, first_episode;
     double eps[kWaveMaxEpisodes][2];
 };

@@ -324,13 +324,12 @@ k_wave_episodes(const WaveArgs a) {
                 if (valid) {
                     lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
                     la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
-                    if (a.counter) {
-                        const int grow_ = (int)srow < W ? lo + (int)srow : ((int)srow == W ? spill0 : spill1);
-                        int32_t* cb = a.counter + (int64_t)g * a.stride + grow_ * A;
-                        atomicAdd(cb + p0.table_off + a0, 1);
-                        atomicAdd(cb + p1.table_off + a1, 1);
-                    }
                 }
+                // visit counters (agents.py:76): the packed transition word goes to this wave's
+                // log (coalesced, L2-resident); the counts are built per game below
+                if (a.counter)
+                    a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + e) * NSEG + seg) * 64 + lane] =
+                        valid ? act[seg] : 0xFFFFFFFFu;
 
                 // ---- (e) replay chain (agents.py:68-76): live next_max, sequential writes.
                 //      Per step: 3 bpermutes fetch this half's reward / old-value term /
@@ -403,6 +402,54 @@ k_wave_episodes(const WaveArgs a) {
             if (lane == 0 && a.n_episodes > 0) a.state[g] = last_price;
         }
         __builtin_amdgcn_wave_barrier();
+
+        // ---- visit counters of this game (agents.py:76).  The tables are back in HBM, so
+        //      the wave's LDS region is free: build the launch's visit histogram there
+        //      (u16 pairs in dwords, ds_add_u32; E*T <= 16*256 < 65536 so no carry) from the
+        //      transition log, then apply it to the counter window with plain coalesced
+        //      read-add-write -- this game's counters belong to this wave alone, so no
+        //      global atomics are needed (2e9 scattered atomics per launch were a 70 ms floor).
+        if (a.counter) {
+            const int cells = (W + 2) * A;                       // per agent
+            const int hw = (cells + 1) >> 1;                     // dwords per agent
+            // may_alias: the histogram overlays the float tables (no type-based reordering)
+            typedef unsigned __attribute__((may_alias)) hist_u32;
+            hist_u32* hist = reinterpret_cast<hist_u32*>(tab0);   // 2*hw dwords <= 2*cells floats
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (int k = lane; k < 2 * hw; k += 64) hist[k] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            for (int e = 0; e < a.n_episodes; e++) {
+#pragma unroll
+                for (int seg = 0; seg < NSEG; seg++) {
+                    // sc1 load (L2-served): the wave reads back what it stored itself
+                    const unsigned w = __hip_atomic_load(
+                        &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + e) * NSEG + seg) * 64 + lane],
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w != 0xFFFFFFFFu) {
+                        const unsigned srow = (w >> 16) & 0xFFu;
+                        const unsigned c0 = srow * (unsigned)A + (w & 0xFFu);
+                        const unsigned c1 = srow * (unsigned)A + ((w >> 8) & 0xFFu);
+                        __hip_atomic_fetch_add(&hist[c0 >> 1], 1u << ((c0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_fetch_add(&hist[hw + (c1 >> 1)], 1u << ((c1 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            int32_t* cw0 = a.counter + (int64_t)g * a.stride + p0.table_off;
+            int32_t* cw1 = a.counter + (int64_t)g * a.stride + p1.table_off;
+            for (int k = lane; k < cells; k += 64) {
+                const int row = k / A, col = k - row * A;
+                const int grow_ = row < W ? lo + row : (row == W ? spill0 : spill1);
+                const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
+                if (grow_ >= 0) {
+                    if (n0) cw0[grow_ * A + col] += (int32_t)n0;
+                    if (n1) cw1[grow_ * A + col] += (int32_t)n1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     a.partial[(size_t)wave_gid * 64 + lane] = acc;
 }
