@@ -69,9 +69,49 @@ __device__ __forceinline__ unsigned bperm(unsigned byte_sel, unsigned v) {
     return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_sel, (int)v);
 }
 
-__device__ __forceinline__ double wave_sum64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP move of a double (two dword moves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+// Sum FOUR per-lane doubles over the 64 lanes in one pass ("transpose" reduction):
+// returns, in every lane L, the wave total of quantity (L & 3) where the quantities are
+// ordered (q0, q1, q2, q3).  7 double adds instead of 24, no LDS traffic.
+__device__ __forceinline__ double wave_sum4(double q0, double q1, double q2, double q3, int lane) {
+    // step 1 (partner lane^1): even lanes keep (q0,q2), odd lanes keep (q1,q3)
+    const bool odd = lane & 1;
+    const double k0 = odd ? q1 : q0, k1 = odd ? q3 : q2;      // kept
+    const double s0 = odd ? q0 : q1, s1 = odd ? q2 : q3;      // what the partner keeps
+    const double a0 = k0 + dpp_mov64<0xB1>(s0);               // quad_perm [1,0,3,2]
+    const double a1 = k1 + dpp_mov64<0xB1>(s1);
+    // step 2 (partner lane^2): bit1 == 0 keeps the first, bit1 == 1 keeps the second
+    const bool b1 = lane & 2;
+    const double kk = b1 ? a1 : a0, ss = b1 ? a0 : a1;
+    double v = kk + dpp_mov64<0x4E>(ss);                      // quad_perm [2,3,0,1]
+    // now lane L holds quantity (L&3) summed over its quad; rotate-add within the 16-lane row
+    v = v + dpp_mov64<0x124>(v);                              // row_ror:4
+    v = v + dpp_mov64<0x128>(v);                              // row_ror:8
+    // across the four rows: swap-add with v_permlane16_swap / v_permlane32_swap
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane16_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane16_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane32_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane32_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
     return v;
 }
 
@@ -185,7 +225,21 @@ k_wave_episodes(const WaveArgs a) {
             const float* s0 = q0 + lo * A;
             const float* s1 = q1 + lo * A;
             const int n = W * A;
-            for (int k = lane; k < n; k += 64) { tab0[k] = s0[k]; tab1[k] = s1[k]; }
+            // 8 loads per agent in flight before the first LDS write (one HBM latency per
+            // batch instead of one per 64 floats)
+            for (int k0 = 0; k0 < n; k0 += 512) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = min(k0 + j * 64 + lane, n - 1);
+                    v0[j] = s0[k]; v1[j] = s1[k];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + j * 64 + lane;
+                    if (k < n) { tab0[k] = v0[j]; tab1[k] = v1[j]; }
+                }
+            }
             if (spill0 >= 0 && lane < A) {
                 tab0[W * A + lane] = q0[spill0 * A + lane];
                 tab1[W * A + lane] = q1[spill0 * A + lane];
@@ -375,12 +429,11 @@ k_wave_episodes(const WaveArgs a) {
                 }
             }
 
-            // ---- (f) per-episode log sums of this game into the wave accumulator
+            // ---- (f) per-episode log sums of this game into the wave accumulator:
+            //      lane L gets the wave total of quantity L&3 = (reward0, reward1, action0, action1)
             {
-                const double w0 = __ddiv_rn(wave_sum64(lr0), inv_T_den), w1 = __ddiv_rn(wave_sum64(lr1), inv_T_den);
-                const double w2 = wave_sum64(la0), w3 = wave_sum64(la1);
-                const int k = lane & 3;
-                const double v = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+                double v = wave_sum4(lr0, lr1, la0, la1, lane);
+                if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
                 if ((lane >> 2) == e) acc += v;
             }
         }
