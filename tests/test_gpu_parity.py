@@ -99,6 +99,38 @@ def test_generic_f32_injected_tracks_reference_within_tolerance():
     assert np.array_equal(gb.counters_numpy()[0], c[0])
 
 
+def test_wave_f32_injected_reference_draws():
+    """The FAST kernel on the reference's own recorded draws (4 reference runs as 4 games):
+    bit-identical to the oracle's float32 mode for all 12 episodes, and against the float64
+    reference itself: identical reward logs (same trajectory) for the first 5 episodes and
+    Q-values within rtol 1e-5."""
+    ds = [np.load(os.path.join(GOLDEN, "g4_cfg_seed%d_e12.npz" % s)) for s in range(4)]
+    config = json.loads(str(ds[0]["config_json"]))
+    q0 = np.stack([d["init_tables"] for d in ds]); s0 = np.array([float(d["state0"]) for d in ds])
+    inj_u = np.ascontiguousarray(np.stack([d["u"] for d in ds], axis=-1))
+    inj_c = np.ascontiguousarray(np.stack([d["choice"] for d in ds], axis=-1))
+    gb = _batch(config, 4, dtype="float32", kernel="wave")
+    gb.set_tables(q0, s0)
+    out5 = gb.run(5, inj=dict(u=inj_u[:5], choice=inj_c[:5]))
+    assert out5["kernel"] == "wave"
+    q5 = gb.tables_numpy().copy()
+    out7 = gb.run(7, inj=dict(u=inj_u[5:], choice=inj_c[5:]))
+    cfg, eps = O.cfg_from_config(config, 4, 0)
+    q = q0.astype(np.float32); c = np.zeros(q.shape, np.int32); s = s0.copy()
+    oo = O.episodes(cfg, q, c, s, eps, O.Memory(cfg), 12, inj_u=inj_u, inj_choice=inj_c)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    np.testing.assert_allclose(np.concatenate([out5["reward_log"], out7["reward_log"]]), oo["reward_log"], rtol=1e-12)
+    # against the float64 reference itself
+    ref_log5 = np.mean([d["rewards_log"][:5] for d in ds], axis=0)
+    np.testing.assert_allclose(out5["reward_log"], ref_log5, rtol=1e-12)
+    cfg64, eps64 = O.cfg_from_config(config, 4, 1)
+    q64 = q0.copy(); c64 = np.zeros(q64.shape, np.int32); s64 = s0.copy()
+    O.episodes(cfg64, q64, c64, s64, eps64, O.Memory(cfg64), 5, inj_u=np.ascontiguousarray(inj_u[:5]),
+               inj_choice=np.ascontiguousarray(inj_c[:5]))
+    np.testing.assert_allclose(q5.astype(np.float64), q64, rtol=1e-5, atol=0)
+
+
 def test_init_matches_oracle():
     gb = _batch(CFG, 50, dtype="float64", seed=11, game_offset=7).init_tables()
     cfg, _ = O.cfg_from_config(CFG, 50, 1)

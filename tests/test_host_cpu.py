@@ -60,7 +60,7 @@ def test_host_logic_layout_and_kernel_selection(lib):
     assert lib.thrl_table_offset(ctypes.byref(cfg), 1) == 101 * 21
     assert lib.thrl_workspace_bytes(ctypes.byref(cfg)) > 0
     assert lib.thrl_select_kernel(ctypes.byref(cfg), 0) == _lib.KERNEL_WAVE
-    assert lib.thrl_select_kernel(ctypes.byref(cfg), 1) == _lib.KERNEL_GENERIC      # injected draws
+    assert lib.thrl_select_kernel(ctypes.byref(cfg), 1) == _lib.KERNEL_WAVE         # injected draws too
     # replay memory holds at most T=100 transitions/agent here: 2*100*G entries * (3*2 + 2*8) bytes
     assert lib.thrl_replay_mem_bytes(ctypes.byref(cfg)) == (1 << 20) * 2 * 100 * 22
     for mod, why in [(dict(q=1), "float32"), (dict(noise=0.05), "noise"), (dict(T=30), "min_memory"),

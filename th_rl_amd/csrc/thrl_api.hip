@@ -143,7 +143,6 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     if (c->n_agents != 2) NO("needs exactly 2 agents");
     if (c->q_dtype != 0) NO("float32 tables only");
     if (c->noise_prob > 0.0) NO("noise_prob > 0");
-    if (injected) NO("injected draws");
     if (c->n_states[0] != c->n_states[1] || c->n_actions[0] != c->n_actions[1] ||
         c->max_state[0] != c->max_state[1]) NO("agents must share the state/action grid sizes");
     const int A = c->n_actions[0], T = c->max_steps;
@@ -312,6 +311,7 @@ static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, 
 }
 
 static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, const WavePlan& p, hipStream_t s) {
+    if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
     if (!b->workspace || b->workspace_bytes < thrl_workspace_bytes(c))
         return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes,
                     thrl_workspace_bytes(c));
@@ -348,6 +348,11 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
         const int n = run->n_episodes - done < kWaveMaxEpisodes ? run->n_episodes - done : kWaveMaxEpisodes;
         a.n_episodes = n;
         a.first_episode = run->first_episode + (uint64_t)done;
+        if (b->inj_u) {                                  // parity mode: this chunk's slice of the draws
+            const size_t per_ep = (size_t)c->max_steps * 2 * (size_t)c->n_games;
+            a.inj_u = b->inj_u + (size_t)done * per_ep;
+            a.inj_choice = b->inj_choice + (size_t)done * per_ep;
+        }
         for (int ep = 0; ep < n; ep++)
             for (int i = 0; i < 2; i++) {
                 a.eps[ep][i] = run->eps[i];

@@ -57,6 +57,8 @@ struct WaveArgs {
     const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
     double* partial;                // device [total_waves][E][4] per-wave log sums
     uint32_t* tlog;                 // device [total_waves][16 episodes][NSEG][64] packed transitions
+    const double* inj_u;            // parity mode: device [n_episodes][T][2][G] uniforms, or null (Philox)
+    const int8_t* inj_choice;       // parity mode: device [n_episodes][T][2][G] random.choice indices
     uint64_t seed, game_offset, first_episode;
     double eps[kWaveMaxEpisodes][2];
 };

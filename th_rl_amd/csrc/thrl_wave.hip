@@ -285,11 +285,22 @@ k_wave_episodes(const WaveArgs a) {
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 const int n = min(64, T - seg * 64);
-                const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
-                const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
-                const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
-                const uint32_t rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) |
-                                    (__umulhi(x.w, (uint32_t)A) << 16);
+                uint32_t rw;
+                if (a.inj_u) {
+                    // parity mode: the reference's recorded draws, [E][T][2][G] (agents.py:81-82)
+                    const int tt = min(seg * 64 + lane, T - 1);
+                    const size_t k = (((size_t)e * T + tt) * 2) * (size_t)a.G + (size_t)g;
+                    const uint32_t ex0 = a.inj_u[k] < eps0 ? 1u : 0u;
+                    const uint32_t ex1 = a.inj_u[k + a.G] < eps1 ? 2u : 0u;
+                    const uint32_t c0 = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(A - 1));
+                    const uint32_t c1 = min((uint32_t)(uint8_t)a.inj_choice[k + a.G], (uint32_t)(A - 1));
+                    rw = ex0 | ex1 | (c0 << 8) | (c1 << 16);
+                } else {
+                    const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
+                    const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
+                    const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
+                    rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) | (__umulhi(x.w, (uint32_t)A) << 16);
+                }
                 rwv[seg] = rw;
                 uint32_t sq = 0;
                 // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
