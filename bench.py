@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--epsilon", type=float, default=None,
+                    help="diagnostic: start from this epsilon instead of the config's 0.5 "
+                         "(e.g. 0.001 = the late-training, greedy-dominated regime)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +111,9 @@ def main():
     chunk = max(1, min(16, args.chunk))
     gb = GameBatch(CFG, n_games=G, device=dev, dtype="float32", kernel=args.kernel, seed=0,
                    game_offset=rank * G, counters=not args.no_counters).init_tables()
+
+    if args.epsilon is not None:
+        gb.eps = [float(args.epsilon)] * len(gb.eps)
 
     def run_steps(n, events=None):
         done = 0
@@ -170,7 +176,7 @@ def main():
                                    "parallel NoisyPriceState games per GPU, T=100, fused step+TD kernel"
                                    % G,
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
-                       "counters": not args.no_counters, "parallelism": "seed-sharded x%d, no collective" % n_gpus},
+                       "counters": not args.no_counters, "epsilon_start": 0.5 if args.epsilon is None else args.epsilon, "parallelism": "seed-sharded x%d, no collective" % n_gpus},
             "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

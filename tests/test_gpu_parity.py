@@ -202,8 +202,7 @@ def test_generic_philox_other_configs_vs_oracle(name, config, dtype):
     """Noise, heterogeneous agents, 3 players with different grids, buffers that
     span episodes / overflow: generic kernel vs oracle, bit for bit, two calls."""
     G, qd = 37, (1 if dtype == "float64" else 0)
-    gb = _batch(config, G, dtype=dtype, seed=4).init_tables()
-    assert gb.planned_kernel() == "generic"
+    gb = _batch(config, G, dtype=dtype, kernel="generic", seed=4).init_tables()
     q0, s0 = gb.tables_numpy(), gb.states_numpy()
     o1 = gb.run(5, per_game_logs=True)
     o2 = gb.run(4, per_game_logs=True)
@@ -216,6 +215,56 @@ def test_generic_philox_other_configs_vs_oracle(name, config, dtype):
     assert np.array_equal(o1["game_reward_log"], oo1["game_reward_log"])
     assert np.array_equal(o2["game_action_log"], oo2["game_action_log"])
     assert list(gb.mem_count[:gb.N]) == list(mem.count[:gb.N])
+
+
+NOISY = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV, noise_prob=0.05)}
+NOISY_HI = {"agents": [dict(CFG_AGENT, action_range=[0.1, 0.6]), dict(CFG_AGENT, gamma=0.35, alpha=0.5, epsilon=0.8)],
+            "environment": dict(CFG_ENV, noise_prob=0.5)}
+
+
+@pytest.mark.parametrize("name,config,G,E", [("hetero_noise", HETERO, 70, 5), ("noise05", NOISY, 333, 20),
+                                             ("noise50_ranges", NOISY_HI, 129, 7)])
+def test_wave_noise_philox_bit_exact_vs_oracle(name, config, G, E):
+    """Environment noise (environments.py:28-31) and per-agent hyper-parameters / action
+    ranges on the fused wave kernel: tables, counters, state bit-identical to the oracle."""
+    gb = _batch(config, G, dtype="float32", kernel="wave", seed=6).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    assert out["kernel"] == "wave"
+    q, c, s, eps, mem, oo = _oracle_run(config, G, 0, q0, s0, E, seed=6)
+    assert np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    assert np.array_equal(gb.tables_numpy(), q)
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12)
+    np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12)
+    # and identical to the generic kernel
+    gg = _batch(config, G, dtype="float32", kernel="generic", seed=6); gg.set_tables(q0, s0); gg.run(E)
+    assert np.array_equal(gg.tables_numpy(), q) and np.array_equal(gg.counters_numpy(), c)
+
+
+def test_wave_noise_injected_reference_run():
+    """The reference's recorded noisy run (noise_prob=0.05, heterogeneous agents, golden G5)
+    on the wave kernel: bit-identical to the oracle's float32 mode over all 20 episodes; same
+    reward log as the float64 reference while the float32 trajectory has not forked (>= 3 episodes)."""
+    d = np.load(os.path.join(GOLDEN, "g5_hetero_noise_seed5_e20.npz"))
+    config = json.loads(str(d["config_json"]))
+    E = d["u"].shape[0]
+    inj = dict(u=np.ascontiguousarray(d["u"][:, :, :, None]), choice=np.ascontiguousarray(d["choice"][:, :, :, None]),
+               noise_u=np.ascontiguousarray(d["noise_u"][:, :, None]),
+               noise_a=np.ascontiguousarray(np.nan_to_num(d["noise_a"][:, :, None])))
+    gb = _batch(config, 1, dtype="float32", kernel="wave")
+    gb.set_tables(d["init_tables"][None, :], [float(d["state0"])])
+    out = gb.run(E, inj=inj)
+    assert out["kernel"] == "wave"
+    cfg, eps = O.cfg_from_config(config, 1, 0)
+    q = d["init_tables"][None, :].astype(np.float32); c = np.zeros(q.shape, np.int32); s = np.array([float(d["state0"])])
+    oo = O.episodes(cfg, q, c, s, eps, O.Memory(cfg), E, inj_u=inj["u"], inj_choice=inj["choice"],
+                    inj_noise_u=inj["noise_u"], inj_noise_a=inj["noise_a"])
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12)
+    same = [np.allclose(out["reward_log"][e], d["rewards_log"][e], rtol=1e-12) for e in range(E)]
+    assert all(same[:3]), same
 
 
 def test_play_greedy_vs_oracle():
@@ -233,7 +282,7 @@ def test_play_greedy_vs_oracle():
 
 def test_wave_forced_on_unsupported_config_fails_loudly():
     from th_rl_amd._lib import ThrlError
-    gb = _batch(HETERO, 8, dtype="float32", kernel="wave").init_tables()
+    gb = _batch(BUFFER, 8, dtype="float32", kernel="wave").init_tables()
     with pytest.raises(ThrlError, match="wave kernel cannot run"):
         gb.run(1)
     with pytest.raises(ThrlError):

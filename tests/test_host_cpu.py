@@ -63,7 +63,10 @@ def test_host_logic_layout_and_kernel_selection(lib):
     assert lib.thrl_select_kernel(ctypes.byref(cfg), 1) == _lib.KERNEL_WAVE         # injected draws too
     # replay memory holds at most T=100 transitions/agent here: 2*100*G entries * (3*2 + 2*8) bytes
     assert lib.thrl_replay_mem_bytes(ctypes.byref(cfg)) == (1 << 20) * 2 * 100 * 22
-    for mod, why in [(dict(q=1), "float32"), (dict(noise=0.05), "noise"), (dict(T=30), "min_memory"),
+    cn = json.loads(json.dumps(CFG)); cn["environment"]["noise_prob"] = 0.05; cn["agents"][0]["alpha"] = 0.5
+    cfgn, _ = _lib.cfg_from_config(cn, 64, 0)
+    assert lib.thrl_select_kernel(ctypes.byref(cfgn), 0) == _lib.KERNEL_WAVE       # noise + per-agent alpha
+    for mod, why in [(dict(q=1), "float32"), (dict(T=30), "min_memory"),
                      (dict(nag=3), "2 agents"), (dict(cap=64), "capacity")]:
         c = json.loads(json.dumps(CFG))
         if "noise" in mod: c["environment"]["noise_prob"] = mod["noise"]

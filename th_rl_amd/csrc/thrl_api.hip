@@ -142,7 +142,6 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
 #define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
     if (c->n_agents != 2) NO("needs exactly 2 agents");
     if (c->q_dtype != 0) NO("float32 tables only");
-    if (c->noise_prob > 0.0) NO("noise_prob > 0");
     if (c->n_states[0] != c->n_states[1] || c->n_actions[0] != c->n_actions[1] ||
         c->max_state[0] != c->max_state[1]) NO("agents must share the state/action grid sizes");
     const int A = c->n_actions[0], T = c->max_steps;
@@ -153,16 +152,27 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
         if (T > c->capacity[i]) NO("max_steps > capacity (deque overflow)");
         if (run && run->mem_count[i] != 0) NO("non-empty replay memory on entry");
     }
+    // Row window = every row a step can land in: both encodes (play: float32, train: float64)
+    // of the price on the whole action grid; with noise the intercept ranges over [0.7a, a).
     int lo = 1 << 30, hi = -1;
+    const double ratio = c->env_a / c->env_b;
     for (int a0 = 0; a0 < A; a0++)
         for (int a1 = 0; a1 < A; a1++) {
-            const double sc[2] = {h_scale(a0, c, 0), h_scale(a1, c, 1)};
-            const double price = h_price(c, sc);
-            const int r64 = h_encode64(price, c, 0), r32 = h_encode32(price, c, 0);
-            if (r64 != r32) NO("float32 and float64 state encodings differ on the action grid");
-            if (r64 < 0 || r64 > c->n_states[0]) NO("price outside the table on the action grid");
-            if (r64 < lo) lo = r64;
-            if (r64 > hi) hi = r64;
+            double Q = 0.0;
+            Q = Q + ratio * h_scale(a0, c, 0);
+            Q = Q + ratio * h_scale(a1, c, 1);
+            const double intercepts[2] = {c->env_a, c->env_a * 0.7};
+            for (int z = 0; z < (c->noise_prob > 0.0 ? 2 : 1); z++) {
+                double price = intercepts[z] - c->env_b * Q;
+                if (!(price > 0.0)) price = 0.0;
+                const int r64 = h_encode64(price, c, 0), r32 = h_encode32(price, c, 0);
+                if (r64 < 0 || r64 > c->n_states[0] || r32 < 0 || r32 > c->n_states[0])
+                    NO("price outside the table on the action grid");
+                if (r64 < lo) lo = r64;
+                if (r32 < lo) lo = r32;
+                if (r64 > hi) hi = r64;
+                if (r32 > hi) hi = r32;
+            }
         }
     p.row_lo = lo;
     p.win_rows = hi - lo + 1;
@@ -312,6 +322,8 @@ static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, 
 
 static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, const WavePlan& p, hipStream_t s) {
     if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
+    if (b->inj_u && c->noise_prob > 0.0 && (!b->inj_noise_u || !b->inj_noise_a))
+        return fail(THRL_ERR_NULL, "noise_prob > 0 with injected draws needs inj_noise_u/inj_noise_a");
     if (!b->workspace || b->workspace_bytes < thrl_workspace_bytes(c))
         return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes,
                     thrl_workspace_bytes(c));
@@ -352,6 +364,10 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
             const size_t per_ep = (size_t)c->max_steps * 2 * (size_t)c->n_games;
             a.inj_u = b->inj_u + (size_t)done * per_ep;
             a.inj_choice = b->inj_choice + (size_t)done * per_ep;
+            if (c->noise_prob > 0.0) {
+                a.inj_noise_u = b->inj_noise_u + (size_t)done * (per_ep / 2);
+                a.inj_noise_a = b->inj_noise_a + (size_t)done * (per_ep / 2);
+            }
         }
         for (int ep = 0; ep < n; ep++)
             for (int i = 0; i < 2; i++) {

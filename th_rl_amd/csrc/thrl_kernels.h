@@ -59,6 +59,8 @@ struct WaveArgs {
     uint32_t* tlog;                 // device [total_waves][16 episodes][NSEG][64] packed transitions
     const double* inj_u;            // parity mode: device [n_episodes][T][2][G] uniforms, or null (Philox)
     const int8_t* inj_choice;       // parity mode: device [n_episodes][T][2][G] random.choice indices
+    const double* inj_noise_u;      // parity mode with noise: device [n_episodes][T][G]
+    const double* inj_noise_a;
     uint64_t seed, game_offset, first_episode;
     double eps[kWaveMaxEpisodes][2];
 };

@@ -150,7 +150,10 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
         double scaled[2] = {scale_action(a0, a.ag[0]), scale_action(a1, a.ag[1])};
         double rew[2];
         const double price = env_step<2>(a.env, 2, scaled, a.env.a, rew);
-        out[L.ns_off + idx] = (unsigned char)(encode64(price, a.ag[0]) - a.row_lo);
+        // next-state row per action pair, window-local: play row (float32 encode, trainer.py:53)
+        // in the low byte, train row (float64 encode, agents.py:62,66) in the high byte
+        reinterpret_cast<unsigned short*>(out + L.ns_off)[idx] =
+            (unsigned short)((encode32(price, a.ag[0]) - a.row_lo) | ((encode64(price, a.ag[0]) - a.row_lo) << 8));
         reinterpret_cast<double*>(out + L.price_off)[idx] = price;
     }
     if (idx < 2 * A) {
@@ -163,8 +166,10 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
 
 // LDS capacity allows 20 resident waves per CU for the headline window, i.e. 5 per
 // SIMD: keep the register allocation at <= 96 VGPRs there (NSEG <= 2).
-template <int NSEG, int NRSEG>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NSEG <= 2 ? 5 : 4)))
+// NOISE: environment noise (environments.py:28-31) handled per step (price not on the LUT);
+// its larger row window leaves room for fewer waves, so the register budget is relaxed.
+template <int NSEG, int NRSEG, bool NOISE>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NOISE ? 3 : (NSEG <= 2 ? 5 : 4))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -178,7 +183,7 @@ k_wave_episodes(const WaveArgs a) {
         for (int k = threadIdx.x; k < (a.lut_bytes >> 2); k += blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
-    const unsigned char* lut_ns = smem + L.ns_off;
+    const unsigned short* lut_ns = reinterpret_cast<const unsigned short*>(smem + L.ns_off);   // play | train<<8
     const double* __restrict__ lut_price = reinterpret_cast<const double*>(a.lut_ns + L.price_off);   // HBM/L2
     const double* lut_aq = reinterpret_cast<const double*>(smem + L.aq_off);
     const double* lut_sct = reinterpret_cast<const double*>(smem + L.sct_off);
@@ -251,12 +256,11 @@ k_wave_episodes(const WaveArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
 
-        int s = sp_l;
+        int s = sp_l | (st_l << 8);          // current state: play row | train row << 8
         double last_price = price0;
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
             const double eps0 = a.eps[e][0], eps1 = a.eps[e][1];
-            const int st_first = (e == 0) ? st_l : s;
 
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
             //          during play: agents.py only writes it in train_net), and the
@@ -282,10 +286,12 @@ k_wave_episodes(const WaveArgs a) {
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
             uint32_t seq[NSEG], rwv[NSEG];
+            double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 const int n = min(64, T - seg * 64);
                 uint32_t rw;
+                nav[seg] = 0.0;
                 if (a.inj_u) {
                     // parity mode: the reference's recorded draws, [E][T][2][G] (agents.py:81-82)
                     const int tt = min(seg * 64 + lane, T - 1);
@@ -301,6 +307,20 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
                     rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) | (__umulhi(x.w, (uint32_t)A) << 16);
                 }
+                if (NOISE) {               // environments.py:28-29, bit 2 of rw = noisy step
+                    double nu, na;
+                    if (a.inj_u) {
+                        const int tt = min(seg * 64 + lane, T - 1);
+                        const size_t k = ((size_t)e * T + tt) * (size_t)a.G + (size_t)g;
+                        nu = a.inj_noise_u[k]; na = a.inj_noise_a[k];
+                    } else {
+                        const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), kStreamNoise);
+                        nu = u01_32(xn.x);
+                        na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
+                    }
+                    if (nu < a.env.noise_prob) rw |= 4u;
+                    nav[seg] = na;
+                }
                 rwv[seg] = rw;
                 uint32_t sq = 0;
                 // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
@@ -313,7 +333,23 @@ k_wave_episodes(const WaveArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t w = readlane_u(rw, min(t0 + j, 63));
-                        if ((w & 3u) == 0u) {
+                        if (NOISE && (w & 4u)) {
+                            // noisy step: the price is not on the LUT; evaluate it for every row
+                            const int tl = min(t0 + j, 63);
+                            const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nav[seg]), tl),
+                                                               __builtin_amdgcn_readlane(__double2loint(nav[seg]), tl));
+                            const uint32_t c0 = (w >> 8) & 0xFFu, c1 = (w >> 16) & 0xFFu;
+#pragma unroll
+                            for (int k = 0; k < NRSEG; k++) {
+                                const uint32_t a0r = (w & 1u) ? c0 : am0[k], a1r = (w & 2u) ? c1 : am1[k];
+                                const double Q = __dadd_rn(lut_aq[a0r], lut_aq[A + a1r]);
+                                double pr = __dsub_rn(na, __dmul_rn(a.env.b, Q));
+                                if (!(pr > 0.0)) pr = 0.0;
+                                const int r32 = min(max(encode32(pr, p0) - lo, 0), W - 1);
+                                const int r64 = min(max(encode64(pr, p0) - lo, 0), W - 1);
+                                nsr[j][k] = (uint32_t)(r32 | (r64 << 8));
+                            }
+                        } else if ((w & 3u) == 0u) {
 #pragma unroll
                             for (int k = 0; k < NRSEG; k++) nsr[j][k] = grow[k];
                         } else {
@@ -329,7 +365,7 @@ k_wave_episodes(const WaveArgs a) {
                     for (int j = 0; j < 4; j++) {
                         if (t0 + j < n) {
                             sq = (lane == t0 + j) ? (uint32_t)s : sq;
-                            s = (int)read_row<NRSEG>(nsr[j], s);
+                            s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
                         }
                     }
                 }
@@ -345,7 +381,8 @@ k_wave_episodes(const WaveArgs a) {
             for (int seg = 0; seg < NSEG; seg++) {
                 const int tt = seg * 64 + lane;
                 const bool valid = tt < T;
-                const uint32_t my_s = seq[seg] & 0xFFu;
+                const uint32_t my_s = seq[seg] & 0xFFu;              // row the step was played in
+                const uint32_t my_train = (seq[seg] >> 8) & 0xFFu;   // row train_net sees for that state
                 const uint32_t rw = rwv[seg];
                 // gather with ALL lanes active (a bpermute reads only from active lanes, and
                 // the source lane here is a table row, unrelated to this lane's step), then select
@@ -355,8 +392,8 @@ k_wave_episodes(const WaveArgs a) {
                 uint32_t a1 = (rw & 2u) ? ((rw >> 16) & 0xFFu) : g1;
                 uint32_t nxt = (uint32_t)__shfl_down((int)seq[seg], 1, 64);
                 if (seg + 1 < NSEG) { if (lane == 63) nxt = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
-                const uint32_t ns = (tt + 1 < T) ? (nxt & 0xFFu) : (uint32_t)s_end;
-                uint32_t srow = (tt == 0) ? (uint32_t)st_first : my_s;
+                const uint32_t ns = (tt + 1 < T) ? ((nxt >> 8) & 0xFFu) : ((uint32_t)s_end >> 8);
+                uint32_t srow = my_train;
                 if (!valid) { a0 = 0; a1 = 0; srow = 0; }
                 const float ov0 = tab0[srow * A + a0];
                 const float ov1 = tab1[srow * A + a1];
@@ -374,7 +411,12 @@ k_wave_episodes(const WaveArgs a) {
                 const bool valid = tt < T;
                 const uint32_t a0 = act[seg] & 0xFFu, a1 = (act[seg] >> 8) & 0xFFu;
                 const uint32_t srow = (act[seg] >> 16) & 0xFFu, ns = act[seg] >> 24;
-                const double price = lut_price[a0 * (uint32_t)A + a1];
+                double price = lut_price[a0 * (uint32_t)A + a1];
+                if (NOISE) {
+                    double pn = __dsub_rn(nav[seg], __dmul_rn(a.env.b, __dadd_rn(lut_aq[a0], lut_aq[A + a1])));
+                    if (!(pn > 0.0)) pn = 0.0;
+                    if (rwv[seg] & 4u) price = pn;
+                }
                 const double r0d = __dmul_rn(price, lut_aq[a0]);
                 const double r1d = __dmul_rn(price, lut_aq[A + a1]);
                 if (seg == NSEG - 1) {
@@ -542,9 +584,9 @@ __global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int 
     }
 }
 
-template <int NSEG, int NRSEG>
+template <int NSEG, int NRSEG, bool NOISE>
 static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((k_wave_episodes<NSEG, NRSEG>), dim3(grid), dim3(block), lds, s, a);
+    hipLaunchKernelGGL((k_wave_episodes<NSEG, NRSEG, NOISE>), dim3(grid), dim3(block), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -554,25 +596,31 @@ int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+template <bool NOISE>
+static int launch_wave_n(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
     const int nrseg = (a.win_rows + 2 + 63) / 64;
     if (nrseg == 1) {
         switch (nseg) {
-            case 1: return launch_wave_t<1, 1>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<2, 1>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<3, 1>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<4, 1>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<1, 1, NOISE>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 1, NOISE>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 1, NOISE>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 1, NOISE>(a, grid, block, lds, s);
         }
     } else if (nrseg == 2) {
         switch (nseg) {
-            case 1: return launch_wave_t<1, 2>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<2, 2>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<3, 2>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<4, 2>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<1, 2, NOISE>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 2, NOISE>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 2, NOISE>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 2, NOISE>(a, grid, block, lds, s);
         }
     }
     return -1;
+}
+
+int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    return a.env.noise_prob > 0.0 ? launch_wave_n<true>(a, grid, block, lds, s)
+                                  : launch_wave_n<false>(a, grid, block, lds, s);
 }
 
 int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,

@@ -6,7 +6,8 @@
 namespace thrl {
 
 struct WaveLut {
-    int ns_off;     // uint8  [A*A]  window-local next-state row per action pair (a0*A+a1)
+    int ns_off;     // uint16 [A*A]  window-local next-state row per action pair (a0*A+a1):
+                    //               play row (float32 encode) | train row (float64 encode) << 8
     int aq_off;     // double [2][A] (a/b)*scale_i(k): quantity of agent i at action k
     int sct_off;    // double [2][A] scale_i(k)/T: per-step contribution to actions_log
     int lds_bytes;  // the part above is staged in LDS (the ns LUT is on the serial chain)
@@ -18,7 +19,7 @@ struct WaveLut {
 __host__ __device__ inline WaveLut wave_lut_layout(int A) {
     WaveLut l;
     l.ns_off = 0;
-    l.aq_off = (A * A + 15) & ~15;
+    l.aq_off = (2 * A * A + 15) & ~15;
     l.sct_off = l.aq_off + 16 * A;
     l.lds_bytes = (l.sct_off + 16 * A + 15) & ~15;
     l.price_off = l.lds_bytes;
