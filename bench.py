@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--noise-prob", type=float, default=None,
+                    help="diagnostic: NoisyPriceState noise_prob (config value 0; class default 0.05)")
     ap.add_argument("--epsilon", type=float, default=None,
                     help="diagnostic: start from this epsilon instead of the config's 0.5 "
                          "(e.g. 0.001 = the late-training, greedy-dominated regime)")
@@ -109,6 +111,8 @@ def main():
 
     G = args.games
     chunk = max(1, min(16, args.chunk))
+    if args.noise_prob is not None:
+        CFG["environment"]["noise_prob"] = float(args.noise_prob)
     gb = GameBatch(CFG, n_games=G, device=dev, dtype="float32", kernel=args.kernel, seed=0,
                    game_offset=rank * G, counters=not args.no_counters).init_tables()
 
@@ -176,7 +180,8 @@ def main():
                                    "parallel NoisyPriceState games per GPU, T=100, fused step+TD kernel"
                                    % G,
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
-                       "counters": not args.no_counters, "epsilon_start": 0.5 if args.epsilon is None else args.epsilon, "parallelism": "seed-sharded x%d, no collective" % n_gpus},
+                       "counters": not args.no_counters, "epsilon_start": 0.5 if args.epsilon is None else args.epsilon,
+                       "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus},
             "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -96,6 +96,48 @@ def test_train_one_batched_games(tmp_path):
     assert np.array_equal(agents[1].table.ravel(), q[0, 2121:].astype(np.float64))
 
 
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    """6 + 9 episodes with a save/load in between == 15 episodes in one go (both kernels,
+    including a config whose replay memory spans episodes)."""
+    from th_rl_amd.batched import GameBatch
+    cfg_a = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV)}
+    cfg_b = {"agents": [dict(CFG_AGENT, min_memory=70, capacity=90), dict(CFG_AGENT)],
+             "environment": dict(CFG_ENV, max_steps=30, noise_prob=0.05)}
+    for config, dtype in ((cfg_a, "float32"), (cfg_b, "float64")):
+        one = GameBatch(config, n_games=50, dtype=dtype, seed=4).init_tables()
+        r_one = one.run(15)
+        a = GameBatch(config, n_games=50, dtype=dtype, seed=4).init_tables()
+        r_a = a.run(6)
+        a.save(str(tmp_path / "ck.pt"))
+        b = GameBatch(config, n_games=50, dtype=dtype, seed=999).load(str(tmp_path / "ck.pt"))
+        assert b.episode == 6 and b.eps == a.eps
+        r_b = b.run(9)
+        assert np.array_equal(b.tables_numpy(), one.tables_numpy())
+        assert np.array_equal(b.counters_numpy(), one.counters_numpy())
+        assert np.array_equal(b.states_numpy(), one.states_numpy())
+        assert b.eps == one.eps and b.episode == 15 and b.mem_count == one.mem_count
+        np.testing.assert_allclose(np.concatenate([r_a["reward_log"], r_b["reward_log"]]), r_one["reward_log"], rtol=1e-12)
+
+
+def test_train_one_resume(tmp_path):
+    import pandas
+    from th_rl_amd import trainer
+    full = _config(8, seed=3, n_games=64, print_freq=500)
+    (tmp_path / "full.json").write_text(json.dumps(full))
+    trainer.train_one(str(tmp_path / "full"), str(tmp_path / "full.json"))
+    first = _config(3, seed=3, n_games=64, print_freq=500)
+    (tmp_path / "first.json").write_text(json.dumps(first))
+    trainer.train_one(str(tmp_path / "first"), str(tmp_path / "first.json"))
+    second = _config(5, seed=3, n_games=64, print_freq=500, resume=str(tmp_path / "first" / "batch.pt"))
+    (tmp_path / "second.json").write_text(json.dumps(second))
+    trainer.train_one(str(tmp_path / "second"), str(tmp_path / "second.json"))
+    for f in ("0.npy", "1.npy", "0_counter.npy", "1_counter.npy"):
+        assert np.array_equal(np.load(tmp_path / "full" / f), np.load(tmp_path / "second" / f)), f
+    lf = pandas.read_csv(tmp_path / "full" / "log.csv", header=[0, 1]).to_numpy()
+    ls = pandas.read_csv(tmp_path / "second" / "log.csv", header=[0, 1]).to_numpy()
+    np.testing.assert_allclose(lf[3:], ls, rtol=1e-12)
+
+
 def test_train_one_rejects_neural_agents(tmp_path):
     from th_rl_amd import trainer
     cfgp = tmp_path / "cfg.json"

@@ -204,6 +204,45 @@ class GameBatch:
             torch.cuda.synchronize(self.device)
         return mr.cpu().numpy(), ma.cpu().numpy()
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything needed to continue the run bit-identically (the reference only saves
+        final tables, trainer.py:101-110): device tensors + the host-side run state."""
+        return {"q": self.q.cpu(), "counter": None if self.counter is None else self.counter.cpu(),
+                "state": self.state.cpu(), "eps": [float(x) for x in self.eps], "episode": int(self.episode),
+                "mem_count": [int(x) for x in self.mem_count], "seed": int(self.seed),
+                "game_offset": int(self.game_offset), "dtype": int(self.dtype), "n_games": int(self.G),
+                "offsets": list(self.offsets), "shapes": [list(x) for x in self.shapes],
+                "replay_mem": None if self.replay_mem is None else self.replay_mem.cpu()}
+
+    def save(self, path):
+        _torch().save(self.state_dict(), path)
+
+    def load_state_dict(self, sd):
+        torch = _torch()
+        if int(sd["n_games"]) != self.G or [list(x) for x in sd["shapes"]] != [list(x) for x in self.shapes] \
+                or int(sd["dtype"]) != self.dtype:
+            raise ThrlError("checkpoint does not match this GameBatch (games / table shapes / dtype)")
+        self.q.copy_(sd["q"])
+        self.state.copy_(sd["state"])
+        if self.counter is not None:
+            if sd["counter"] is None:
+                self.counter.zero_()
+            else:
+                self.counter.copy_(sd["counter"])
+        self.eps = [float(x) for x in sd["eps"]]
+        self.episode = int(sd["episode"])
+        self.mem_count = [int(x) for x in sd["mem_count"]]
+        self.seed, self.game_offset = int(sd["seed"]), int(sd["game_offset"])
+        if sd.get("replay_mem") is not None:
+            self._ensure_replay_mem()
+            self.replay_mem.copy_(sd["replay_mem"])
+        self.initialized = True
+        return self
+
+    def load(self, path):
+        return self.load_state_dict(_torch().load(path, weights_only=True))
+
     # ------------------------------------------------------------------ download
     def tables_numpy(self):
         return self.q.cpu().numpy()

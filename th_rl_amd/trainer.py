@@ -9,7 +9,8 @@ kernels).  The JSON schema is the reference's; the optional extra keys in the
                  "n_games": 1,        # games trained in lockstep (independent replicas)
                  "seed": null,        # Philox seed (null: drawn from numpy's global RNG)
                  "dtype": null,       # "float64" | "float32" (default f64 for 1 game, f32 otherwise)
-                 "device": "cuda:0", "game_offset": 0, "kernel": "auto"}
+                 "device": "cuda:0", "game_offset": 0, "kernel": "auto",
+                 "resume": null}     # path of a batch.pt written by an earlier run: continue it
 
 n_games == 1: tables come from the constructed agents (numpy's global RNG, exactly where
 the reference draws them) and the run is float64.  n_games > 1: every game's tables and
@@ -73,7 +74,10 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
                       seed=seed, game_offset=int(training.get("game_offset", 0)),
                       kernel=training.get("kernel", "auto"))
-    if n_games == 1:
+    resume = training.get("resume", None)
+    if resume:
+        batch.load(resume)                              # tables, counters, state, epsilon, episode index
+    elif n_games == 1:
         state = environment.reset()                     # drawn once, as trainer.py:45
         batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
     else:
@@ -113,12 +117,8 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     log = pandas.concat([rpd, apd], axis=1, keys=["rewards", "actions"])
     log.to_csv(os.path.join(exp_path, "log.csv"), index=None)
 
-    if n_games > 1:
-        import torch
-        torch.save({"q": batch.q.cpu(), "counter": None if batch.counter is None else batch.counter.cpu(),
-                    "state": batch.state.cpu(), "eps": list(batch.eps), "episode": batch.episode,
-                    "seed": seed, "game_offset": batch.game_offset, "offsets": batch.offsets,
-                    "shapes": batch.shapes}, os.path.join(exp_path, "batch.pt"))
+    if n_games > 1 or resume or training.get("checkpoint", False):
+        batch.save(os.path.join(exp_path, "batch.pt"))
 
 
 # BASELINE.json's north_star names the entry point "trainer.train()"; the reference's is train_one.
