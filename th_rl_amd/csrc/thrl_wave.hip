@@ -524,31 +524,50 @@ k_wave_episodes(const WaveArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             for (int k = lane; k < 2 * hw; k += 64) hist[k] = 0u;
             __builtin_amdgcn_wave_barrier();
-            for (int e = 0; e < a.n_episodes; e++) {
+            // log read-back: 4 episodes' loads in flight at a time (sc1 = L2-served: the wave
+            // reads what it stored itself)
+            for (int e0 = 0; e0 < a.n_episodes; e0 += 4) {
+                unsigned w[4][NSEG];
 #pragma unroll
-                for (int seg = 0; seg < NSEG; seg++) {
-                    // sc1 load (L2-served): the wave reads back what it stored itself
-                    const unsigned w = __hip_atomic_load(
-                        &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + e) * NSEG + seg) * 64 + lane],
-                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w != 0xFFFFFFFFu) {
-                        const unsigned srow = (w >> 16) & 0xFFu;
-                        const unsigned c0 = srow * (unsigned)A + (w & 0xFFu);
-                        const unsigned c1 = srow * (unsigned)A + ((w >> 8) & 0xFFu);
-                        __hip_atomic_fetch_add(&hist[c0 >> 1], 1u << ((c0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        __hip_atomic_fetch_add(&hist[hw + (c1 >> 1)], 1u << ((c1 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int seg = 0; seg < NSEG; seg++)
+                        w[j][seg] = __hip_atomic_load(
+                            &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + min(e0 + j, a.n_episodes - 1)) * NSEG + seg) * 64 + lane],
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int seg = 0; seg < NSEG; seg++) {
+                        const unsigned ww = w[j][seg];
+                        if (e0 + j < a.n_episodes && ww != 0xFFFFFFFFu) {
+                            const unsigned srow = (ww >> 16) & 0xFFu;
+                            const unsigned c0 = srow * (unsigned)A + (ww & 0xFFu);
+                            const unsigned c1 = srow * (unsigned)A + ((ww >> 8) & 0xFFu);
+                            __hip_atomic_fetch_add(&hist[c0 >> 1], 1u << ((c0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_add(&hist[hw + (c1 >> 1)], 1u << ((c1 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
                     }
-                }
             }
             __builtin_amdgcn_wave_barrier();
+            // apply: window rows are contiguous in HBM, so cell k of the window is element
+            // lo*A + k of the agent's table (no row/column split); spill rows separately
             int32_t* cw0 = a.counter + (int64_t)g * a.stride + p0.table_off;
             int32_t* cw1 = a.counter + (int64_t)g * a.stride + p1.table_off;
-            for (int k = lane; k < cells; k += 64) {
-                const int row = k / A, col = k - row * A;
-                const int grow_ = row < W ? lo + row : (row == W ? spill0 : spill1);
+            const int nwin = W * A;
+            for (int k = lane; k < nwin; k += 64) {
                 const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
                 const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
+                if (n0) cw0[lo * A + k] += (int32_t)n0;
+                if (n1) cw1[lo * A + k] += (int32_t)n1;
+            }
+            if (lane < 2 * A) {
+                const int which = lane >= A, col = lane - which * A;
+                const int grow_ = which ? spill1 : spill0;
+                const int k = nwin + lane;
                 if (grow_ >= 0) {
+                    const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                    const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
                     if (n0) cw0[grow_ * A + col] += (int32_t)n0;
                     if (n1) cw1[grow_ * A + col] += (int32_t)n1;
                 }
