@@ -267,6 +267,56 @@ def test_wave_noise_injected_reference_run():
     assert all(same[:3]), same
 
 
+def _shape_config(T, A=21, states=100, rng=(0.2, 0.4), noise=0.0, cap=500):
+    ag = dict(CFG_AGENT, actions=A, states=states, action_range=list(rng), min_memory=min(T, 100), capacity=cap)
+    return {"agents": [dict(ag), dict(ag, alpha=0.3)], "environment": dict(CFG_ENV, max_steps=T, noise_prob=noise)}
+
+
+@pytest.mark.parametrize("label,config,G,E", [
+    ("T1", _shape_config(1), 40, 17),                      # NSEG=1, single step, 17 episodes = 16 + 1 chunks
+    ("T37", _shape_config(37), 33, 5),
+    ("T64", _shape_config(64), 33, 5),                     # exactly one segment
+    ("T65", _shape_config(65), 33, 5),                     # one step into the second segment
+    ("T128", _shape_config(128), 21, 3),
+    ("T129", _shape_config(129), 21, 3),                   # NSEG=3
+    ("T200", _shape_config(200), 13, 3),                   # NSEG=4
+    ("T256", _shape_config(256), 9, 2),
+    ("A2", _shape_config(50, A=2), 33, 6),                 # smallest action grid
+    ("A32", _shape_config(50, A=32), 33, 4),               # all 32 lanes of a half
+    ("fullwindow", _shape_config(100, rng=(0.0, 0.5)), 19, 4),          # 101 reachable rows: NRSEG=2
+    ("fullwindow_noise_T130", _shape_config(130, rng=(0.0, 0.5), noise=0.2), 11, 3),
+    ("states16", _shape_config(30, A=4, states=16, rng=(0.0, 1.0)), 50, 6),   # QTable ctor defaults grid
+    ("one_game", _shape_config(100), 1, 3),
+])
+def test_wave_shapes_vs_oracle(label, config, G, E):
+    """Every template variant of the wave kernel (episode length 1..256 -> 1-4 step segments,
+    1-2 row segments, 2..32 actions, noise) against the oracle, bit for bit."""
+    gb = _batch(config, G, dtype="float32", kernel="wave", seed=12).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    assert out["kernel"] == "wave"
+    q, c, s, eps, mem, oo = _oracle_run(config, G, 0, q0, s0, E, seed=12)
+    assert np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    assert np.array_equal(gb.tables_numpy(), q)
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13)
+
+
+def test_zero_episodes_and_odd_sizes():
+    """Empty and ragged inputs: 0 episodes is a no-op; G far below / not a multiple of the
+    resident wave count."""
+    gb = _batch(CFG, 3, kernel="wave", seed=1).init_tables()
+    q0 = gb.tables_numpy().copy()
+    out = gb.run(0)
+    assert out["reward_log"].shape == (0, 2) and np.array_equal(gb.tables_numpy(), q0) and gb.episode == 0
+    gb = _batch(CFG, 5121, kernel="wave", seed=1).init_tables()       # one more game than resident waves
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    gb.run(2)
+    q, c, s, eps, mem, oo = _oracle_run(CFG, 5121, 0, q0, s0, 2, seed=1)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+
+
 def test_play_greedy_vs_oracle():
     gb = _batch(CFG, 64, dtype="float32", seed=1).init_tables()
     gb.run(3)
