@@ -119,6 +119,13 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// v = lane `lane` of `old` replaced by the (uniform) value `val`: one v_writelane_b32 with the
+// lane select in M0 (two different SGPR operands would break the gfx9 constant-bus limit)
+__device__ __forceinline__ uint32_t writelane_u(uint32_t old, uint32_t val, int lane) {
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane));
+    return old;
+}
+
 // value of a lane-indexed-by-row register pair at (uniform) row s
 template <int NRSEG>
 __device__ __forceinline__ uint32_t read_row(const uint32_t (&r)[NRSEG], int s) {
@@ -364,7 +371,7 @@ k_wave_episodes(const WaveArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (t0 + j < n) {
-                            sq = (lane == t0 + j) ? (uint32_t)s : sq;
+                            sq = writelane_u(sq, (uint32_t)s, t0 + j);
                             s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
                         }
                     }
