@@ -33,7 +33,7 @@ ALGO_BYTES_PER_ENV_STEP = 368.0     # 2 agents x (2 x 21
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_baseline(seconds_target=10.0):
     """The oracle (CPU port of the reference loop, float32 mode) timed on the host
     cores, on a bounded sample of the SAME workload (same config, Philox draws)."""
     import numpy as np
@@ -44,23 +44,22 @@ def cpu_baseline(seconds_target=12.0):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    E = 8
-    g_per = 512                     # ~1 s per worker at ~4e6 env-steps/s/core, then scaled
+    games = 1024                    # per thread: 17 MB of tables, cache-friendly like the reference's 1 game
     O.lib()                         # build/load before timing
 
-    def work(k, games):
+    def work(k, episodes):
         cfg, eps = O.cfg_from_config(CFG, games, 0)
         q, c, s = O.init(cfg, seed=0, game_offset=k * games)
         mem = O.Memory(cfg)
         t0 = time.perf_counter()
-        O.episodes(cfg, q, c, s, eps, mem, E, seed=0, game_offset=k * games)   # ctypes releases the GIL
+        O.episodes(cfg, q, c, s, eps, mem, episodes, seed=0, game_offset=k * games)   # ctypes releases the GIL
         return time.perf_counter() - t0
 
-    t_probe = work(0, g_per)
-    games = max(64, int(g_per * seconds_target / max(t_probe, 1e-3)))
+    t_probe = work(0, 4)
+    E = max(4, int(4 * seconds_target / max(t_probe, 1e-3)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda k: work(k, games), range(cores)))
+        list(ex.map(lambda k: work(k, E), range(cores)))
     wall = time.perf_counter() - t0
     steps = cores * games * E * T_STEPS
     return dict(value=steps / wall, unit="env-steps/s", cores=cores, kind="port",
@@ -79,7 +78,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--noise-prob", type=float, default=None,
                     help="diagnostic: NoisyPriceState noise_prob (config value 0; class default 0.05)")
     ap.add_argument("--epsilon", type=float, default=None,

@@ -317,6 +317,25 @@ def test_zero_episodes_and_odd_sizes():
     assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
 
 
+def test_learning_outcome_matches_reference_statistics():
+    """Statistical parity in Philox mode: the reference's seeded 10,000-epoch
+    2xQTable run ends at reward ~ 12.1-12.2 and scaled action ~ 0.29 per agent (above the Nash
+    11.11: tacit collusion).  The mean over 512 independently seeded games must land there."""
+    gb = _batch(CFG, 512, kernel="wave", seed=123).init_tables()
+    first = gb.run(500)
+    for _ in range(18):
+        gb.run(500, logs=False)
+    last = gb.run(500)
+    assert gb.episode == 10000 and abs(gb.eps[0] - (0.001 + 0.499 * 0.9995 ** 10000)) < 1e-12
+    r, a = last["reward_log"].mean(axis=0), last["action_log"].mean(axis=0)
+    assert np.all(r > 11.9) and np.all(r < 12.3), r
+    assert np.all(a > 0.280) and np.all(a < 0.295), a
+    assert np.all(first["reward_log"].mean(axis=0) < 11.5)            # it actually learned
+    mr, ma = gb.play_greedy(iters=1)
+    total = mr.sum(axis=1).mean()
+    assert 22.22 < total < 25.0, total                                  # between Nash and cartel
+
+
 def test_play_greedy_vs_oracle():
     gb = _batch(CFG, 64, dtype="float32", seed=1).init_tables()
     gb.run(3)
