@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Golden fixture G7 for the neural policy path: runs the REFERENCE's Reinforce agent
+(th_rl/agents.py:119-220) here, records data only.  Usage: python tests/golden/make_golden_nn.py
+
+Recorded: seeded initial parameters (torch default Linear init), action probabilities on
+probe states (pi(), agents.py:147-151), two consecutive train_net() calls (agents.py:170-194)
+on 1,000 appended transitions each: clipped gradients left in .grad, Adam state
+(exp_avg, exp_avg_sq, step) and the parameters afterwards; get_action on probe states.
+"""
+import os
+import random
+import sys
+
+import numpy
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+import th_rl.agents as ref_agents  # noqa: E402
+
+PARAMS = ["fc1.weight", "fc1.bias", "fc_pi.weight", "fc_pi.bias"]
+
+
+def flat(d):
+    return numpy.concatenate([d[k].detach().numpy().ravel() for k in PARAMS]).astype("float32")
+
+
+def main():
+    torch.set_num_threads(1)
+    out = {}
+    for tag, kw in (("cfg", dict(gamma=0.995, actions=21, states=1, action_range=[0.2, 0.4])),
+                    ("ent", dict(gamma=0.35, actions=21, states=1, action_range=[0.2, 0.4], entropy=0.01))):
+        numpy.random.seed(3); random.seed(3); torch.manual_seed(3)
+        ag = ref_agents.Reinforce(**kw)
+        sd0 = {k: v.clone() for k, v in ag.state_dict().items()}
+        out[tag + "_w0"] = flat(sd0)
+        probe = numpy.linspace(2.0, 6.0, 9)
+        out[tag + "_probe_price"] = probe
+        with torch.no_grad():
+            out[tag + "_probe_prob0"] = numpy.stack(
+                [ag.pi(torch.from_numpy(numpy.array([p]).astype("float32"))).numpy() for p in probe])
+        rs = numpy.random.RandomState(11)
+        for call in range(2):
+            price = rs.randint(20, 61, size=1001) / 10.0          # on the env's price grid
+            action = rs.randint(0, 21, size=1000)
+            reward = rs.uniform(5, 15, size=1000)
+            for t in range(1000):
+                ag.memory.append(numpy.array([price[t]]), numpy.int64(action[t]), float(reward[t]), True,
+                                 numpy.array([price[t + 1]]))
+            ag.train_net()
+            assert len(ag.memory) == 0
+            named = dict(ag.named_parameters())
+            out["%s_c%d_price" % (tag, call)] = price
+            out["%s_c%d_action" % (tag, call)] = action.astype("int64")
+            out["%s_c%d_reward" % (tag, call)] = reward
+            out["%s_c%d_grad" % (tag, call)] = numpy.concatenate(
+                [named[k].grad.numpy().ravel() for k in PARAMS]).astype("float32")
+            st = ag.optimizer.state
+            out["%s_c%d_m" % (tag, call)] = numpy.concatenate(
+                [st[named[k]]["exp_avg"].numpy().ravel() for k in PARAMS]).astype("float32")
+            out["%s_c%d_v" % (tag, call)] = numpy.concatenate(
+                [st[named[k]]["exp_avg_sq"].numpy().ravel() for k in PARAMS]).astype("float32")
+            out["%s_c%d_step" % (tag, call)] = numpy.float64(float(st[named[PARAMS[0]]]["step"]))
+            out["%s_c%d_w" % (tag, call)] = flat(ag.state_dict())
+        with torch.no_grad():
+            out[tag + "_probe_prob2"] = numpy.stack(
+                [ag.pi(torch.from_numpy(numpy.array([p]).astype("float32"))).numpy() for p in probe])
+        out[tag + "_probe_greedy2"] = numpy.array([ag.get_action(numpy.array([p])) for p in probe], "int64")
+        out[tag + "_scale"] = numpy.array([ag.scale(k) for k in range(21)])
+        out[tag + "_kw"] = numpy.array(repr(kw))
+    p = os.path.join(HERE, "g7_reinforce.npz")
+    numpy.savez_compressed(p, **out)
+    print("wrote", p, os.path.getsize(p))
+
+
+if __name__ == "__main__":
+    main()
