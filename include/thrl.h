@@ -183,6 +183,40 @@ int thrl_op_td_update(const thrl_cfg* cfg, int agent, void* q, int32_t* counter,
                       const double* price, const int32_t* action, const double* reward,
                       const double* next_price, double* scratch, void* stream);
 
+/*
+ * Neural policy agent `Reinforce` (agents.py:119-220): a 1 -> 256 -> A MLP per game.
+ * Parameter vector per game, P = thrl_nn_param_count(A) floats:
+ *   [fc1.weight (256) | fc1.bias (256) | fc_pi.weight (A x 256 row-major) | fc_pi.bias (A)]
+ * All arrays are device pointers, game-major ([G][P]) for parameters and Adam moments,
+ * transition-major ([n][G]) for the replayed buffer.  float32 arithmetic as in torch.
+ */
+#define THRL_NN_HIDDEN 256
+#define THRL_NN_MAX_TRANSITIONS 1400
+size_t thrl_nn_param_count(int n_actions);
+/* torch.nn.Linear default init, U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases
+ * (agents.py:136-137), from Philox keyed by (seed, global game id, agent). */
+int thrl_nn_init(int n_games, int n_actions, float* params, uint64_t seed, uint64_t game_offset,
+                 int agent, void* stream);
+/* Reinforce.pi + sample_action / get_action (agents.py:147-168) for G games: price [G] f64
+ * (cast to float32 as the trainer does, trainer.py:53); u [G] uniforms in [0,1) for the
+ * categorical draw (inverse CDF), or NULL for the greedy get_action; outputs action [G] and
+ * optionally the probabilities [G][A]. */
+int thrl_nn_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
+                int32_t* action_out, float* prob_out, void* stream);
+/* Reinforce.train_net's update (agents.py:171-193) for G games on n replayed transitions each:
+ * discounted returns, z-score (unbiased std), policy-gradient + entropy loss, gradient-norm clip
+ * at 1.0, one Adam step (lr, betas 0.9/0.999, eps 1e-8).  step = Adam step count BEFORE the call.
+ * grad_out [G][P] (optional) receives the clipped gradient. */
+int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
+                            int32_t step, int32_t n, const double* price, const int32_t* action,
+                            const double* reward, double gamma, double entropy_coef, double lr,
+                            float* grad_out, void* stream);
+/* Philox draws for one lockstep step of a caller-driven loop: u [N][G] f64 uniforms and
+ * choice [N][G] int8 indices (agents.py:81-82), optionally the env's two noise draws [G]
+ * (environments.py:28-29); same streams/counters as thrl_qtable_episodes uses internally. */
+int thrl_op_draws(const thrl_cfg* cfg, uint64_t seed, uint64_t game_offset, uint64_t episode, int32_t step,
+                  double* u_out, int8_t* choice_out, double* noise_u_out, double* noise_a_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

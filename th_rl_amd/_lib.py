@@ -60,6 +60,7 @@ SYMBOLS = [
     "thrl_replay_mem_bytes", "thrl_workspace_bytes", "thrl_select_kernel", "thrl_qtable_init",
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
+    "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
 ]
 
 _lib = None
@@ -120,6 +121,17 @@ def load():
     L.thrl_op_scale.argtypes = [cfgp, ctypes.c_int, vp, vp, vp]
     L.thrl_op_td_update.restype = ctypes.c_int
     L.thrl_op_td_update.argtypes = [cfgp, ctypes.c_int, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.thrl_nn_param_count.restype = ctypes.c_size_t
+    L.thrl_nn_param_count.argtypes = [ctypes.c_int]
+    L.thrl_nn_init.restype = ctypes.c_int
+    L.thrl_nn_init.argtypes = [ctypes.c_int, ctypes.c_int, vp, u64, u64, ctypes.c_int, vp]
+    L.thrl_nn_act.restype = ctypes.c_int
+    L.thrl_nn_act.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    L.thrl_nn_reinforce_train.restype = ctypes.c_int
+    L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp,
+                                          dbl, dbl, dbl, vp, vp]
+    L.thrl_op_draws.restype = ctypes.c_int
+    L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp]
     if L.thrl_version() != 1:
         raise ThrlError("th_rl_amd: ABI version mismatch (%d)" % L.thrl_version())
     _lib = L

@@ -505,4 +505,62 @@ int thrl_op_td_update(const thrl_cfg* c, int agent, void* q, int32_t* counter, i
     return e ? hip_fail(e, "k_op_td launch") : THRL_OK;
 }
 
+size_t thrl_nn_param_count(int n_actions) {
+    if (n_actions < 2 || n_actions > 32) return 0;
+    return (size_t)(2 * THRL_NN_HIDDEN + n_actions * THRL_NN_HIDDEN + n_actions);
+}
+
+static int nn_check(int n_games, int n_actions) {
+    if (n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", n_games);
+    if (n_actions < 2 || n_actions > 32) return fail(THRL_ERR_BAD_CONFIG, "neural agent: actions=%d out of [2,32]", n_actions);
+    return THRL_OK;
+}
+
+int thrl_nn_init(int n_games, int n_actions, float* params, uint64_t seed, uint64_t game_offset, int agent,
+                 void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params) return fail(THRL_ERR_NULL, "params is NULL");
+    const int e = launch_nn_init(n_games, n_actions, params, seed, game_offset, agent, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_init launch") : THRL_OK;
+}
+
+int thrl_nn_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
+                int32_t* action_out, float* prob_out, void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params || !price || !action_out) return fail(THRL_ERR_NULL, "params/price/action_out is NULL");
+    const int e = launch_nn_act(n_games, n_actions, params, price, u, action_out, prob_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_act launch") : THRL_OK;
+}
+
+int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step,
+                            int32_t n, const double* price, const int32_t* action, const double* reward,
+                            double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params || !adam_m || !adam_v || !price || !action || !reward) return fail(THRL_ERR_NULL, "a required pointer is NULL");
+    if (n < 2 || n > THRL_NN_MAX_TRANSITIONS)
+        return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions out of [2,%d]", n, THRL_NN_MAX_TRANSITIONS);
+    if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
+    if (nn_train_lds_bytes(n_actions, n) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
+    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward,
+                                  (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
+}
+
+int thrl_op_draws(const thrl_cfg* c, uint64_t seed, uint64_t game_offset, uint64_t episode, int32_t step,
+                  double* u_out, int8_t* choice_out, double* noise_u_out, double* noise_a_out, void* stream) {
+    int rc = validate(c);
+    if (rc) return rc;
+    if (!u_out || !choice_out) return fail(THRL_ERR_NULL, "u_out/choice_out is NULL");
+    if ((noise_u_out == nullptr) != (noise_a_out == nullptr)) return fail(THRL_ERR_NULL, "noise outputs must both be given or both NULL");
+    int32_t nA[THRL_MAXA];
+    for (int i = 0; i < THRL_MAXA; i++) nA[i] = i < c->n_agents ? c->n_actions[i] : 1;
+    const int e = launch_op_draws(c->n_games, c->n_agents, seed, game_offset, (uint32_t)episode, (uint32_t)step,
+                                  c->env_a, c->env_a * 0.7, nA, u_out, choice_out, noise_u_out, noise_a_out,
+                                  (hipStream_t)stream);
+    return e ? hip_fail(e, "k_op_draws launch") : THRL_OK;
+}
+
 }  // extern "C"

@@ -112,4 +112,15 @@ int launch_op_scale(const OpArgs& a, hipStream_t s);
 int launch_op_encode(const OpArgs& a, hipStream_t s);
 int launch_op_td(const OpArgs& a, int q_dtype, hipStream_t s);
 
+// ---- neural policy agent (thrl_nn.hip)
+int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s);
+int launch_nn_act(int G, int A, const float* params, const double* price, const double* u, int32_t* act,
+                  float* prob, hipStream_t s);
+size_t nn_train_lds_bytes(int A, int N);
+int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
+                    const int32_t* action, const double* reward, float gamma, float ent, float lr, float* grad,
+                    hipStream_t s);
+int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
+                    double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* nu, double* na, hipStream_t s);
+
 }  // namespace thrl

@@ -1,0 +1,84 @@
+"""ReinforceBatch: the reference's `Reinforce` agent (th_rl/agents.py:119-220) for G games at once.
+Per-game independent 1 -> 256 -> A MLPs, their Adam state and step counter live in HBM; acting and
+training run in libthrl_hip.so (thrl_nn_*).  float32, as torch."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import ThrlError
+from .batched import _require_gpu, _torch
+
+
+class ReinforceBatch:
+    def __init__(self, n_games, actions=2, gamma=0.98, entropy=0.0, lr=2e-4, device="cuda:0", seed=0,
+                 game_offset=0, agent_index=0):
+        self.L = _lib.load()
+        torch = _torch()
+        self.device = _require_gpu(device)
+        self.G, self.A = int(n_games), int(actions)
+        self.gamma, self.entropy, self.lr = float(gamma), float(entropy), float(lr)
+        self.seed, self.game_offset, self.agent_index = int(seed), int(game_offset), int(agent_index)
+        self.P = int(self.L.thrl_nn_param_count(self.A))
+        if self.P == 0:
+            raise ThrlError("Reinforce on the device needs 2 <= actions <= 32, got %d" % self.A)
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros((self.G, self.P), dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        self.step = 0
+
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _dev(self, a, dtype):
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    def init(self):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.thrl_nn_init(self.G, self.A, self._p(self.params), self.seed, self.game_offset,
+                                           self.agent_index, self._stream()), "thrl_nn_init")
+        self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
+        return self
+
+    def set_params(self, w):
+        w = np.asarray(w, np.float32).reshape(-1, self.P)
+        self.params.copy_(self._dev(np.broadcast_to(w, (self.G, self.P)), _torch().float32))
+        return self
+
+    def act(self, price, u=None, want_probs=False):
+        """actions int32 [G] (device tensor); u=None -> greedy get_action."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            d_price = self._dev(price, torch.float64).reshape(self.G)
+            d_u = None if u is None else self._dev(u, torch.float64).reshape(self.G)
+            out = torch.zeros((self.G,), dtype=torch.int32, device=self.device)
+            probs = torch.zeros((self.G, self.A), dtype=torch.float32, device=self.device) if want_probs else None
+            _lib.check(self.L.thrl_nn_act(self.G, self.A, self._p(self.params), self._p(d_price), self._p(d_u),
+                                          self._p(out), self._p(probs), self._stream()), "thrl_nn_act")
+        return (out, probs) if want_probs else out
+
+    def train(self, price, action, reward, want_grad=False):
+        """One train_net update on n transitions per game: arrays [n, G]."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
+            d_a = self._dev(action, torch.int32).reshape(n, self.G)
+            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
+            d_p = d_p.reshape(n, self.G)
+            grad = torch.zeros_like(self.params) if want_grad else None
+            _lib.check(self.L.thrl_nn_reinforce_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
+                                                      self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a),
+                                                      self._p(d_r), self.gamma, self.entropy, self.lr,
+                                                      self._p(grad), self._stream()), "thrl_nn_reinforce_train")
+            torch.cuda.synchronize(self.device)
+        self.step += 1
+        return grad
