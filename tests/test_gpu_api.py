@@ -138,13 +138,13 @@ def test_train_one_resume(tmp_path):
     np.testing.assert_allclose(lf[3:], ls, rtol=1e-12)
 
 
-def test_train_one_rejects_neural_agents(tmp_path):
+def test_train_one_rejects_unbuilt_neural_agents(tmp_path):
     from th_rl_amd import trainer
     cfgp = tmp_path / "cfg.json"
     c = _config(2)
-    c["agents"][1] = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
+    c["agents"][1] = {"name": "ActorCritic", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
     cfgp.write_text(json.dumps(c))
-    with pytest.raises(NotImplementedError, match="neural agents"):
+    with pytest.raises(NotImplementedError, match="ActorCritic"):
         trainer.train_one(str(tmp_path / "r"), str(cfgp))
 
 

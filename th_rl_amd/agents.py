@@ -6,9 +6,9 @@ once goes through GameBatch / train_one instead.  Host-side state (`table`,
 `counter`, `epsilon`, `memory`) keeps the reference's attribute names so
 utils.load_experiment / plot_qagent style consumers keep working.
 
-The neural agents (Reinforce / ActorCritic / CAC) are constructible so that the
-reference's example configs load, but their compute methods are not part of this
-round's scope and raise NotImplementedError.
+Reinforce acts and trains on the device too.  ActorCritic and CAC
+are constructible so that configs naming them load, but their compute methods raise
+NotImplementedError (not built yet).
 """
 from collections import namedtuple
 import random
@@ -172,13 +172,70 @@ class _NeuralAgentBase(nn.Module):
 
 
 class Reinforce(_NeuralAgentBase):
+    """The reference's REINFORCE agent (agents.py:119-220).  The torch modules hold the parameters
+    (so state_dict / save / load keep the reference's format); acting and train_net run on the GPU
+    through thrl_nn_act / thrl_nn_reinforce_train (one game per call here; many games at once
+    through th_rl_amd.nn.ReinforceBatch / mixed.MixedGameBatch)."""
+
     def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
                  capacity=50000, min_memory=1000, entropy=0, **kwargs):
         super().__init__()
+        self.data = []
         self.fc1 = nn.Linear(states, 256)
         self.fc_pi = nn.Linear(256, actions)
         self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
         self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
+        self.states = states
+        self._rb = None
+
+    # -- device plumbing ---------------------------------------------------------
+    def flat_params(self):
+        return numpy.concatenate([self.fc1.weight.detach().numpy().ravel(), self.fc1.bias.detach().numpy().ravel(),
+                                  self.fc_pi.weight.detach().numpy().ravel(),
+                                  self.fc_pi.bias.detach().numpy().ravel()]).astype("float32")
+
+    def set_flat_params(self, w):
+        w = numpy.asarray(w, "float32")
+        A = self.actions
+        with torch.no_grad():
+            self.fc1.weight.copy_(torch.from_numpy(w[:256].reshape(256, 1).copy()))
+            self.fc1.bias.copy_(torch.from_numpy(w[256:512].copy()))
+            self.fc_pi.weight.copy_(torch.from_numpy(w[512:512 + A * 256].reshape(A, 256).copy()))
+            self.fc_pi.bias.copy_(torch.from_numpy(w[512 + A * 256:].copy()))
+
+    def _device(self):
+        if self.states != 1:
+            raise _lib.ThrlError("Reinforce on the device needs states == 1")
+        if self._rb is None:
+            from .nn import ReinforceBatch
+            self._rb = ReinforceBatch(1, actions=self.actions, gamma=self.gamma, entropy=self.entropy)
+        self._rb.gamma, self._rb.entropy = float(self.gamma), float(self.entropy)
+        self._rb.set_params(self.flat_params())
+        return self._rb
+
+    # -- reference protocol ------------------------------------------------------
+    def pi(self, x, softmax_dim=0):
+        """Action probabilities for one state tensor (1,) -- evaluated on the device."""
+        rb = self._device()
+        _, probs = rb.act(numpy.asarray(x, dtype="float64").reshape(1), want_probs=True)
+        return probs[0].cpu()
+
+    def sample_action(self, state):
+        u = float(torch.rand(()))                    # the categorical draw (inverse CDF on the device)
+        return int(self._device().act(numpy.asarray(state, dtype="float64").reshape(1), u=[u]).cpu()[0])
+
+    def get_action(self, state):
+        return int(self._device().act(numpy.asarray(state, dtype="float64").reshape(1)).cpu()[0])
+
+    def train_net(self):
+        if len(self.memory) >= self.min_memory:
+            states, actions, rewards, done, s_prime = self.memory.replay()
+            n = len(actions)
+            rb = self._device()
+            rb.train(numpy.array(states, dtype="float64").reshape(n, 1), numpy.array(actions).reshape(n, 1),
+                     numpy.array(rewards, dtype="float64").reshape(n, 1))
+            self.set_flat_params(rb.params.cpu().numpy()[0])
+            self.memory.empty()
 
 
 class ActorCritic(_NeuralAgentBase):
@@ -188,6 +245,7 @@ class ActorCritic(_NeuralAgentBase):
         self.fc1 = nn.Linear(states, 256)
         self.fc_pi = nn.Linear(256, actions)
         self.fc_v = nn.Linear(256, 1)
+        self.fc_v.bias.data.fill_(1000.0)
         self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
         self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
 

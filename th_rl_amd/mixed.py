@@ -1,0 +1,224 @@
+"""MixedGameBatch: G games whose agents may be any mix of QTable and Reinforce (the pairing the
+reference's own example configs use), stepped in lockstep with the UNFUSED device operators of
+libthrl_hip.so -- the same call sequence as trainer.train_one's loop (th_rl/trainer.py:46-70),
+one launch per reference call, applied to all games at once:
+
+    thrl_op_draws -> thrl_op_sample_action | thrl_nn_act -> thrl_op_scale -> thrl_op_env_step
+    -> (append) -> per episode thrl_op_td_update | thrl_nn_reinforce_train
+
+All-QTable configs should use GameBatch (fused kernels, ~20x faster); this path exists so that
+configs with neural agents run on the device too.  The random streams are the ones the fused
+kernels use, so an all-QTable game gives bit-identical tables on both paths.
+torch is used for device memory and for three one-line float64 element-wise expressions
+(Reinforce.scale and the two log accumulations).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import ThrlError
+from .batched import _require_gpu, _torch
+from .nn import ReinforceBatch
+
+NN_DEFAULTS = dict(states=4, actions=2, action_range=[0, 1], gamma=0.98, capacity=50000, min_memory=1000,
+                   entropy=0)
+
+
+class MixedGameBatch:
+    def __init__(self, config, n_games=1, device="cuda:0", dtype="float32", seed=0, game_offset=0):
+        self.L = _lib.load()
+        torch = _torch()
+        self.device = _require_gpu(device)
+        self.config = config
+        self.G = int(n_games)
+        self.seed, self.game_offset = int(seed), int(game_offset)
+        self.dtype = {"float32": 0, "float64": 1}[str(dtype)]
+        self.kinds = [a.get("name", "QTable") for a in config["agents"]]
+        for k in self.kinds:
+            if k not in ("QTable", "Reinforce"):
+                raise NotImplementedError("device path: agent %r is not supported (QTable, Reinforce)" % k)
+        # thrl_cfg for the operators: a Reinforce agent occupies a dummy 2-row table slot
+        as_q = []
+        self.nn_cfg = {}
+        for i, a in enumerate(config["agents"]):
+            if self.kinds[i] == "QTable":
+                as_q.append(dict(a))
+            else:
+                p = dict(NN_DEFAULTS, **a)
+                if int(p["states"]) != 1:
+                    raise ThrlError("Reinforce on the device needs states == 1 (the env state is one number)")
+                self.nn_cfg[i] = p
+                as_q.append(dict(name="QTable", states=1, actions=int(p["actions"]), action_range=p["action_range"],
+                                 capacity=1, min_memory=1))
+        qconf = {"agents": as_q, "environment": config["environment"]}
+        self.cfg, eps = _lib.cfg_from_config(qconf, self.G, self.dtype)
+        self.N, self.T = self.cfg.n_agents, self.cfg.max_steps
+        self.eps = list(eps)
+        self.stride = int(self.L.thrl_table_stride(ctypes.byref(self.cfg)))
+        self.offsets = [int(self.L.thrl_table_offset(ctypes.byref(self.cfg), i)) for i in range(self.N)]
+        self.shapes = [(self.cfg.n_states[i] + 1, self.cfg.n_actions[i]) for i in range(self.N)]
+        tdt = torch.float64 if self.dtype == 1 else torch.float32
+        with torch.cuda.device(self.device):
+            self.q = torch.zeros((self.G, self.stride), dtype=tdt, device=self.device)
+            self.counter = torch.zeros((self.G, self.stride), dtype=torch.int32, device=self.device)
+            self.state = torch.zeros((self.G,), dtype=torch.float64, device=self.device)
+        self.nn = {i: ReinforceBatch(self.G, actions=int(p["actions"]), gamma=float(p["gamma"]),
+                                     entropy=float(p["entropy"]), device=device, seed=seed, game_offset=game_offset,
+                                     agent_index=i) for i, p in self.nn_cfg.items()}
+        self.cap = [int(self.cfg.capacity[i]) if self.kinds[i] == "QTable" else int(self.nn_cfg[i]["capacity"])
+                    for i in range(self.N)]
+        self.min_memory = [int(self.cfg.min_memory[i]) if self.kinds[i] == "QTable" else int(self.nn_cfg[i]["min_memory"])
+                           for i in range(self.N)]
+        # replay buffers hold at most min_memory + T - 1 entries before a train call empties them
+        self.buf_len = [min(self.cap[i], self.min_memory[i] + self.T) if self.cap[i] >= self.min_memory[i] else self.cap[i]
+                        for i in range(self.N)]
+        with torch.cuda.device(self.device):
+            self.buf = [dict(price=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
+                             action=torch.zeros((max(n, 1), self.G), dtype=torch.int32, device=self.device),
+                             reward=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
+                             nprice=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device))
+                        for n in self.buf_len]
+        self.count = [0] * self.N            # appends since the last empty()
+        self.episode = 0
+        self.initialized = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+    def init_tables(self):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.thrl_qtable_init(ctypes.byref(self.cfg), self._p(self.q), self._p(self.counter),
+                                               self._p(self.state), self.seed, self.game_offset, self._stream()),
+                       "thrl_qtable_init")
+        for rb in self.nn.values():
+            rb.init()
+        self.initialized = True
+        return self
+
+    def set_tables(self, q, state):
+        torch = _torch()
+        self.q.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(q).reshape(self.G, self.stride))).to(self.q.dtype))
+        self.state.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(state, np.float64).reshape(self.G))))
+        self.counter.zero_()
+        self.initialized = True
+        return self
+
+    def states_numpy(self):
+        return self.state.cpu().numpy()
+
+    def tables_numpy(self):
+        return self.q.cpu().numpy()
+
+    def counters_numpy(self):
+        return self.counter.cpu().numpy()
+
+    def table(self, game, agent):
+        r, a = self.shapes[agent]; o = self.offsets[agent]
+        return self.q[game, o:o + r * a].cpu().numpy().astype(np.float64).reshape(r, a)
+
+    def counter_of(self, game, agent):
+        r, a = self.shapes[agent]; o = self.offsets[agent]
+        return self.counter[game, o:o + r * a].cpu().numpy().astype(np.float64).reshape(r, a)
+
+    # ------------------------------------------------------------------ the step loop
+    def _append(self, i, price, action, reward, nprice):
+        cap = self.buf_len[i]
+        if cap <= 0:
+            return
+        pos = self.count[i] % cap
+        b = self.buf[i]
+        b["price"][pos].copy_(price); b["action"][pos].copy_(action)
+        b["reward"][pos].copy_(reward); b["nprice"][pos].copy_(nprice)
+        self.count[i] += 1
+        if self.count[i] >= 2 * cap:
+            self.count[i] -= cap
+
+    def _ordered(self, i):
+        """Buffer contents in insertion order (deque semantics), as contiguous [n, G] tensors."""
+        torch = _torch()
+        cap = self.buf_len[i]
+        n = min(self.count[i], cap)
+        start = 0 if self.count[i] <= cap else self.count[i] % cap
+        b = self.buf[i]
+        if start == 0:
+            return n, {k: v[:n].contiguous() for k, v in b.items()}
+        idx = (torch.arange(n, device=self.device) + start) % cap
+        return n, {k: v.index_select(0, idx).contiguous() for k, v in b.items()}
+
+    def run(self, n_episodes):
+        torch = _torch()
+        if not self.initialized:
+            raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
+        E, N, G, T = int(n_episodes), self.N, self.G, self.T
+        cfg = ctypes.byref(self.cfg)
+        L = self.L
+        noise = self.cfg.noise_prob > 0
+        with torch.cuda.device(self.device):
+            rlog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
+            alog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
+            u = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            ch = torch.zeros((N, G), dtype=torch.int8, device=self.device)
+            nu = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
+            na = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
+            acts = torch.zeros((N, G), dtype=torch.int32, device=self.device)
+            scaled = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            nprice = torch.zeros((G,), dtype=torch.float64, device=self.device)
+            reward = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            price = self.state
+            # a tensor divisor: torch turns "/ python_scalar" into "* (1/scalar)", which is not the
+            # reference's IEEE division
+            T_t = torch.tensor(float(T), dtype=torch.float64, device=self.device)
+            for e in range(E):
+                for t in range(T):
+                    _lib.check(L.thrl_op_draws(cfg, self.seed, self.game_offset, self.episode, t, self._p(u), self._p(ch),
+                                               self._p(nu), self._p(na), self._stream()), "thrl_op_draws")
+                    for i in range(N):
+                        if self.kinds[i] == "QTable":
+                            _lib.check(L.thrl_op_sample_action(cfg, i, self._p(self.q), self._p(price), self.eps[i],
+                                                               self._p(u[i]), self._p(ch[i]), 1, self._p(acts[i]),
+                                                               self._stream()), "thrl_op_sample_action")
+                            _lib.check(L.thrl_op_scale(cfg, i, self._p(acts[i]), self._p(scaled[i]), self._stream()),
+                                       "thrl_op_scale")
+                        else:
+                            rb = self.nn[i]
+                            acts[i].copy_(rb.act(price, u=u[i]))
+                            lo, hi = [float(x) for x in self.nn_cfg[i]["action_range"]]
+                            # Reinforce.scale (agents.py:153-157): action / actions * (hi - lo) + lo
+                            A_t = torch.tensor(float(rb.A), dtype=torch.float64, device=self.device)
+                            scaled[i].copy_(torch.div(acts[i].to(torch.float64), A_t) * (hi - lo) + lo)
+                    _lib.check(L.thrl_op_env_step(cfg, self._p(scaled), self._p(nu), self._p(na), self._p(nprice),
+                                                  self._p(reward), self._stream()), "thrl_op_env_step")
+                    for i in range(N):
+                        self._append(i, price, acts[i], reward[i], nprice)
+                    rlog[e] += torch.div(reward, T_t)           # trainer.py:65
+                    alog[e] += torch.div(scaled, T_t)           # trainer.py:66
+                    price = nprice.clone()
+                for i in range(N):                              # [A.train_net() for A in agents]
+                    n, b = self._ordered(i)
+                    if n >= self.min_memory[i] and n > 0:
+                        if self.kinds[i] == "QTable":
+                            scratch = torch.zeros((n, G), dtype=torch.float64, device=self.device)
+                            _lib.check(L.thrl_op_td_update(cfg, i, self._p(self.q), self._p(self.counter), n,
+                                                           self._p(b["price"]), self._p(b["action"]), self._p(b["reward"]),
+                                                           self._p(b["nprice"]), self._p(scratch), self._stream()),
+                                       "thrl_op_td_update")
+                            torch.cuda.synchronize(self.device)
+                        else:
+                            self.nn[i].train(b["price"], b["action"], b["reward"])
+                        self.count[i] = 0
+                    if self.kinds[i] == "QTable":                # epsilon decays on every call (agents.py:78)
+                        self.eps[i] = self.cfg.eps_end[i] + (self.eps[i] - self.cfg.eps_end[i]) * self.cfg.eps_step[i]
+                self.episode += 1
+            self.state.copy_(price)
+            torch.cuda.synchronize(self.device)
+            out = dict(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy(), kernel="unfused")
+        out["reward_log"] = out["game_reward_log"].mean(axis=2)
+        out["action_log"] = out["game_action_log"].mean(axis=2)
+        return out

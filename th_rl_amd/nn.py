@@ -51,7 +51,7 @@ class ReinforceBatch:
 
     def set_params(self, w):
         w = np.asarray(w, np.float32).reshape(-1, self.P)
-        self.params.copy_(self._dev(np.broadcast_to(w, (self.G, self.P)), _torch().float32))
+        self.params.copy_(self._dev(np.broadcast_to(w, (self.G, self.P)).copy(), _torch().float32))
         return self
 
     def act(self, price, u=None, want_probs=False):

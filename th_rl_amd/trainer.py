@@ -56,10 +56,11 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         os.mkdir(os.path.join(exp_path))
 
     config, agents, environment = create_game(configpath)
-    if not all(isinstance(a, QTable) for a in agents) or not isinstance(environment, NoisyPriceState):
+    if not all(isinstance(a, (QTable, Reinforce)) for a in agents) or not isinstance(environment, NoisyPriceState):
         raise NotImplementedError(
-            "train_one: the device path trains QTable agents on NoisyPriceState; "
-            "neural agents are outside this round's scope (SURVEY.md section 8f)")
+            "train_one: the device path trains QTable and Reinforce agents on NoisyPriceState; "
+            "ActorCritic / CAC are not built yet (SURVEY.md section 8f)")
+    all_tabular = all(isinstance(a, QTable) for a in agents)
 
     training = config.get("training", {})
     epochs = training.get("epochs", 0)
@@ -71,15 +72,32 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     dtype = training.get("dtype", None) or ("float64" if n_games == 1 else "float32")
     names = [a["name"] for a in config["agents"]]
 
-    batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
-                      seed=seed, game_offset=int(training.get("game_offset", 0)),
-                      kernel=training.get("kernel", "auto"))
     resume = training.get("resume", None)
+    if all_tabular:
+        batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
+                          seed=seed, game_offset=int(training.get("game_offset", 0)),
+                          kernel=training.get("kernel", "auto"))
+    else:
+        # games with neural agents: the unfused batched operator loop (mixed.py)
+        from th_rl_amd.mixed import MixedGameBatch
+        if resume:
+            raise NotImplementedError("resume is available for all-QTable configs only")
+        batch = MixedGameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
+                               seed=seed, game_offset=int(training.get("game_offset", 0)))
     if resume:
         batch.load(resume)                              # tables, counters, state, epsilon, episode index
     elif n_games == 1:
         state = environment.reset()                     # drawn once, as trainer.py:45
-        batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
+        if all_tabular:
+            batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
+        else:
+            flat = numpy.zeros((1, batch.stride))
+            for i, a in enumerate(agents):
+                if isinstance(a, QTable):
+                    flat[0, batch.offsets[i]:batch.offsets[i] + a.table.size] = a.table.ravel()
+                else:
+                    batch.nn[i].set_params(a.flat_params())     # torch's default init, as in the reference
+            batch.set_tables(flat, [float(state[0])])
     else:
         batch.init_tables()
 
@@ -103,9 +121,12 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
 
     # Store result: the reference's artefacts, from game 0
     for i, a in enumerate(agents):
-        a.table = batch.table(0, i)
-        a.counter = batch.counter_of(0, i)
-        a.epsilon = batch.eps[i]
+        if isinstance(a, QTable):
+            a.table = batch.table(0, i)
+            a.counter = batch.counter_of(0, i)
+            a.epsilon = batch.eps[i]
+        else:
+            a.set_flat_params(batch.nn[i].params[0].cpu().numpy())
         a.save(os.path.join(exp_path, str(i)))
     environment.state = numpy.float64(batch.states_numpy()[0])
 
@@ -117,7 +138,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     log = pandas.concat([rpd, apd], axis=1, keys=["rewards", "actions"])
     log.to_csv(os.path.join(exp_path, "log.csv"), index=None)
 
-    if n_games > 1 or resume or training.get("checkpoint", False):
+    if all_tabular and (n_games > 1 or resume or training.get("checkpoint", False)):
         batch.save(os.path.join(exp_path, "batch.pt"))
 
 
