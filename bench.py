@@ -67,6 +67,29 @@ def cpu_baseline(seconds_target=10.0):
                        "Philox draws, %.1f s" % (cores * games, E, T_STEPS, cores, games, wall))
 
 
+def bench_nn(args):
+    """BASELINE configs[3]: 2 Reinforce agents (agents.py:119-220) x 65,536 games, unfused operator
+    loop (mixed.MixedGameBatch).  steps = episodes; the policy trains every 10 episodes."""
+    import torch
+    from th_rl_amd.mixed import MixedGameBatch
+    G = args.games if args.games != (1 << 20) else 65536
+    ag = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
+    config = {"agents": [dict(ag), dict(ag)], "environment": dict(CFG["environment"])}
+    mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=0).init_tables()
+    mb.run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mb.run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "env-steps/sec, 2-agent neural policy (Reinforce) x %d games" % G,
+                      "value": G * T_STEPS * args.steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                      "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                      "config": {"workload": "2-agent Reinforce x %d games, unfused operator loop, MFMA off" % G,
+                                 "network_updates": mb.nn[0].step}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +98,9 @@ def main():
     ap.add_argument("--games", type=int, default=1 << 20, help="games per GPU")
     ap.add_argument("--chunk", type=int, default=10, help="episodes per kernel launch (<=16)")
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
+    ap.add_argument("--workload", default="qtable", choices=["qtable", "nn"],
+                    help="qtable = the headline metric (default); nn = BASELINE configs[3]: 2 Reinforce "
+                         "agents x 65,536 games through the unfused operator loop (secondary)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
@@ -92,6 +118,9 @@ def main():
     n_gpus = args.gpus
     if world != n_gpus and world > 1:
         n_gpus = world
+
+    if args.workload == "nn":
+        return bench_nn(args)
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

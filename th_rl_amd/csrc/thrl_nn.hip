@@ -78,7 +78,13 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
     }
 }
 
-// train_net for one game per block (agents.py:171-193)
+// train_net for one game per block (agents.py:171-193).
+// The n transitions are processed in chunks of kChunk: pass A (thread = transition of the chunk)
+// does the forward pass and dL/dlogits into LDS, pass B (thread = hidden unit) accumulates that
+// unit's column of every gradient over the chunk.  Chunking keeps LDS at ~50 KB per block, so
+// three blocks (12 waves) share a CU instead of one.
+constexpr int kChunk = 256;
+
 __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
@@ -90,8 +96,8 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     float* b2s = b1s + kH;                                  // [kMaxA]
     float* xs = b2s + kMaxA;                                // [N]
     float* Gs = xs + N;                                     // [N]
-    float* dz = Gs + N;                                     // [N][A]
-    float* red = dz + (size_t)N * A;                        // [8]
+    float* dz = Gs + N;                                     // [kChunk][A]
+    float* red = dz + (size_t)kChunk * A;                   // [8]
     const int g = blockIdx.x, tid = threadIdx.x;
     const int P = 2 * kH + A * kH + A;
     float* w = params + (int64_t)g * P;
@@ -117,65 +123,69 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     for (int n = tid; n < N; n += 256) Gs[n] = (Gs[n] - mean) / sd;
     __syncthreads();
 
-    // pass A (thread = transition): forward, d loss / d logits
     const float invN = 1.0f / (float)N;
-    for (int n = tid; n < N; n += 256) {
-        const float x = xs[n];
-        float zz[kMaxA];
-#pragma unroll
-        for (int k = 0; k < kMaxA; k++) zz[k] = k < A ? b2s[k] : -INFINITY;
-        for (int j = 0; j < kH; j++) {
-            const float hj = fmaxf(__fmaf_rn(w1s[j], x, b1s[j]), 0.0f);
-#pragma unroll
-            for (int k = 0; k < kMaxA; k++)
-                if (k < A) zz[k] = __fmaf_rn(W2[k * kH + j], hj, zz[k]);
-        }
-        float m = zz[0];
-#pragma unroll
-        for (int k = 1; k < kMaxA; k++) if (k < A) m = fmaxf(m, zz[k]);
-        float sum = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kMaxA; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
-        float Hn = 0.0f;
-        float lp[kMaxA];
-#pragma unroll
-        for (int k = 0; k < kMaxA; k++)
-            if (k < A) {
-                zz[k] = zz[k] / sum;
-                lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
-                Hn -= zz[k] * lp[k];
-            }
-        const int a_n = action[(size_t)n * G + g];
-        const float Gn = Gs[n];
-#pragma unroll
-        for (int k = 0; k < kMaxA; k++)
-            if (k < A)
-                dz[(size_t)n * A + k] = (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN;
-    }
-    __syncthreads();
-
-    // pass B (thread = hidden unit j): gradients of fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j]
     float gW2[kMaxA], col[kMaxA];
 #pragma unroll
     for (int k = 0; k < kMaxA; k++) { gW2[k] = 0.0f; col[k] = k < A ? W2[k * kH + tid] : 0.0f; }
-    float gw1 = 0.0f, gb1 = 0.0f;
+    float gw1 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
     const float w1j = w1s[tid], b1j = b1s[tid];
-    for (int n = 0; n < N; n++) {
-        const float x = xs[n];
-        const float pre = __fmaf_rn(w1j, x, b1j);
-        const float hj = fmaxf(pre, 0.0f);
-        float dh = 0.0f;
+
+    for (int c0 = 0; c0 < N; c0 += kChunk) {
+        const int cn = min(kChunk, N - c0);
+        // pass A (thread = transition): forward, d loss / d logits
+        if (tid < cn) {
+            const int n = c0 + tid;
+            const float x = xs[n];
+            float zz[kMaxA];
 #pragma unroll
-        for (int k = 0; k < kMaxA; k++)
-            if (k < A) {
-                const float d = dz[(size_t)n * A + k];
-                gW2[k] = __fmaf_rn(d, hj, gW2[k]);
-                dh = __fmaf_rn(col[k], d, dh);
+            for (int k = 0; k < kMaxA; k++) zz[k] = k < A ? b2s[k] : -INFINITY;
+            for (int j = 0; j < kH; j++) {
+                const float hj = fmaxf(__fmaf_rn(w1s[j], x, b1s[j]), 0.0f);
+#pragma unroll
+                for (int k = 0; k < kMaxA; k++)
+                    if (k < A) zz[k] = __fmaf_rn(W2[k * kH + j], hj, zz[k]);
             }
-        if (pre > 0.0f) { gw1 = __fmaf_rn(dh, x, gw1); gb1 += dh; }
+            float m = zz[0];
+#pragma unroll
+            for (int k = 1; k < kMaxA; k++) if (k < A) m = fmaxf(m, zz[k]);
+            float sum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMaxA; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
+            float Hn = 0.0f;
+            float lp[kMaxA];
+#pragma unroll
+            for (int k = 0; k < kMaxA; k++)
+                if (k < A) {
+                    zz[k] = zz[k] / sum;
+                    lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
+                    Hn -= zz[k] * lp[k];
+                }
+            const int a_n = action[(size_t)n * G + g];
+            const float Gn = Gs[n];
+#pragma unroll
+            for (int k = 0; k < kMaxA; k++)
+                if (k < A)
+                    dz[tid * A + k] = (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN;
+        }
+        __syncthreads();
+        // pass B (thread = hidden unit j): fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j]
+        for (int i = 0; i < cn; i++) {
+            const float x = xs[c0 + i];
+            const float pre = __fmaf_rn(w1j, x, b1j);
+            const float hj = fmaxf(pre, 0.0f);
+            float dh = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMaxA; k++)
+                if (k < A) {
+                    const float d = dz[i * A + k];
+                    gW2[k] = __fmaf_rn(d, hj, gW2[k]);
+                    dh = __fmaf_rn(col[k], d, dh);
+                }
+            if (pre > 0.0f) { gw1 = __fmaf_rn(dh, x, gw1); gb1 += dh; }
+        }
+        if (tid < A) for (int i = 0; i < cn; i++) gb2 += dz[i * A + tid];
+        __syncthreads();
     }
-    float gb2 = 0.0f;
-    if (tid < A) for (int n = 0; n < N; n++) gb2 += dz[(size_t)n * A + tid];
 
     // clip_grad_norm_(1.0) (agents.py:192)
     float sq = gw1 * gw1 + gb1 * gb1 + (tid < A ? gb2 * gb2 : 0.0f);
@@ -239,7 +249,7 @@ int launch_nn_act(int G, int A, const float* params, const double* price, const 
     return (int)hipGetLastError();
 }
 size_t nn_train_lds_bytes(int A, int N) {
-    return sizeof(float) * ((size_t)A * kH + 2 * kH + kMaxA + 2 * (size_t)N + (size_t)N * A + 8);
+    return sizeof(float) * ((size_t)A * kH + 2 * kH + kMaxA + 2 * (size_t)N + (size_t)kChunk * A + 8);
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, float gamma, float ent, float lr, float* grad,
