@@ -293,6 +293,7 @@ k_wave_episodes(const WaveArgs a) {
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
             uint32_t seq[NSEG], rwv[NSEG];
+            uint32_t kwv[NSEG];            // per step: flags | K << 8, K = (f0 ? c0*A : 0) + (f1 ? c1 : 0)
             double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
@@ -329,6 +330,9 @@ k_wave_episodes(const WaveArgs a) {
                     nav[seg] = na;
                 }
                 rwv[seg] = rw;
+                const uint32_t kw = (rw & 7u) |
+                    ((((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) + ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u)) << 8);
+                kwv[seg] = kw;
                 uint32_t sq = 0;
                 // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
                 // for every row r the next row if step t were played in r,
@@ -339,7 +343,7 @@ k_wave_episodes(const WaveArgs a) {
                     uint32_t nsr[4][NRSEG];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t w = readlane_u(rw, min(t0 + j, 63));
+                        const uint32_t w = readlane_u(NOISE ? rw : kw, min(t0 + j, 63));
                         if (NOISE && (w & 4u)) {
                             // noisy step: the price is not on the LUT; evaluate it for every row
                             const int tl = min(t0 + j, 63);
@@ -360,11 +364,21 @@ k_wave_episodes(const WaveArgs a) {
 #pragma unroll
                             for (int k = 0; k < NRSEG; k++) nsr[j][k] = grow[k];
                         } else {
-                            const uint32_t c0A = ((w >> 8) & 0xFFu) * (uint32_t)A, c1 = (w >> 16) & 0xFFu;
+                            if (NOISE) {
+                                const uint32_t c0A = ((w >> 8) & 0xFFu) * (uint32_t)A, c1 = (w >> 16) & 0xFFu;
 #pragma unroll
-                            for (int k = 0; k < NRSEG; k++) {
-                                const uint32_t idx = ((w & 1u) ? c0A : am0A[k]) + ((w & 2u) ? c1 : am1[k]);
-                                nsr[j][k] = lut_ns[idx];
+                                for (int k = 0; k < NRSEG; k++) {
+                                    const uint32_t idx = ((w & 1u) ? c0A : am0A[k]) + ((w & 2u) ? c1 : am1[k]);
+                                    nsr[j][k] = lut_ns[idx];
+                                }
+                            } else {
+                                // idx = greedy part (masked by the not-exploring flags) + precomputed K
+                                const uint32_t nf0 = (w & 1u) ^ 1u, nf1 = ((w >> 1) & 1u) ^ 1u, K = w >> 8;
+#pragma unroll
+                                for (int k = 0; k < NRSEG; k++) {
+                                    const uint32_t idx = __umul24(am0A[k], nf0) + __umul24(am1[k], nf1) + K;
+                                    nsr[j][k] = lut_ns[idx];
+                                }
                             }
                         }
                     }
