@@ -382,11 +382,19 @@ k_wave_episodes(const WaveArgs a) {
                             }
                         }
                     }
+                    if (t0 + 4 <= n) {          // full group: no per-step bound checks on the chain
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (t0 + j < n) {
+                        for (int j = 0; j < 4; j++) {
                             sq = writelane_u(sq, (uint32_t)s, t0 + j);
                             s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (t0 + j < n) {
+                                sq = writelane_u(sq, (uint32_t)s, t0 + j);
+                                s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
+                            }
                         }
                     }
                 }
