@@ -273,6 +273,7 @@ k_wave_episodes(const WaveArgs a) {
             //          during play: agents.py only writes it in train_net), and the
             //          greedy-greedy successor row of every row
             uint32_t am0[NRSEG], am1[NRSEG], am0A[NRSEG], grow[NRSEG];
+            uint32_t am0A2[NRSEG], am1x2[NRSEG];      // byte offsets into the u16 LUT (x2), for the play loop
 #pragma unroll
             for (int k = 0; k < NRSEG; k++) {
                 const int row = min(lane + 64 * k, W + 1);
@@ -287,6 +288,7 @@ k_wave_episodes(const WaveArgs a) {
                     if (v1 > b1) { b1 = v1; i1 = j; }
                 }
                 am0[k] = i0; am1[k] = i1; am0A[k] = i0 * (uint32_t)A;
+                am0A2[k] = am0A[k] * 2u; am1x2[k] = i1 * 2u;
                 grow[k] = lut_ns[i0 * (uint32_t)A + i1];
             }
 
@@ -373,11 +375,12 @@ k_wave_episodes(const WaveArgs a) {
                                 }
                             } else {
                                 // idx = greedy part (masked by the not-exploring flags) + precomputed K
-                                const uint32_t nf0 = (w & 1u) ^ 1u, nf1 = ((w >> 1) & 1u) ^ 1u, K = w >> 8;
+                                const uint32_t nf0 = (w & 1u) ^ 1u, nf1 = ((w >> 1) & 1u) ^ 1u, K2 = (w >> 8) << 1;
 #pragma unroll
                                 for (int k = 0; k < NRSEG; k++) {
-                                    const uint32_t idx = __umul24(am0A[k], nf0) + __umul24(am1[k], nf1) + K;
-                                    nsr[j][k] = lut_ns[idx];
+                                    const uint32_t off = __umul24(am0A2[k], nf0) + __umul24(am1x2[k], nf1) + K2;
+                                    nsr[j][k] = *reinterpret_cast<const unsigned short*>(
+                                        reinterpret_cast<const unsigned char*>(lut_ns) + off);
                                 }
                             }
                         }
