@@ -94,6 +94,16 @@ typedef struct {
     const double* inj_noise_a;       /* device [n_episodes][T][G]    (environments.py:29) */
     void*    workspace;              /* device scratch, thrl_workspace_bytes()           */
     size_t   workspace_bytes;
+    /* Per-game hyper-parameter sweeps (optional; NULL = thrl_cfg's scalar for every game): the
+     * reference sweeps configs x runs one process at a time (main.py:13-21); here a sweep is a
+     * per-game array.  Device, layout [N][G] (agent-major); fused wave kernel only. */
+    const double* sweep_gamma;       /* QTable gamma  (agents.py:30)                     */
+    const double* sweep_alpha;       /* QTable alpha  (agents.py:31)                     */
+    const double* sweep_eps_end;     /* agents.py:37                                     */
+    const double* sweep_eps_step;    /* agents.py:36                                     */
+    double*       sweep_eps;         /* in/out: current epsilon per (agent, game); when given it
+                                        replaces thrl_run.eps (agents.py:35,78)          */
+    const double* sweep_noise_prob;  /* device [G]; thrl_cfg.noise_prob must be > 0 if any entry is */
 } thrl_buffers;
 
 /* Host-side run state that is identical for every game (so it never lives in HBM). */

@@ -182,7 +182,7 @@ class Memory:
 
 
 def episodes(cfg, q, counter, state, eps, mem, n_episodes, seed=0, game_offset=0, first_episode=0,
-             inj_u=None, inj_choice=None, inj_noise_u=None, inj_noise_a=None, trace=False):
+             inj_u=None, inj_choice=None, inj_noise_u=None, inj_noise_a=None, trace=False, sweep=None):
     """Run n_episodes of all games in place.  Returns dict of logs."""
     G, N, T = cfg.n_games, cfg.n_agents, cfg.max_steps
     g_r = np.zeros((n_episodes, N, G)); g_a = np.zeros((n_episodes, N, G))
@@ -201,7 +201,9 @@ def episodes(cfg, q, counter, state, eps, mem, n_episodes, seed=0, game_offset=0
         _p(mem.s), _p(mem.a), _p(mem.ns), _p(mem.r), ctypes.c_int32(mem.capmax),
         ctypes.c_uint64(seed), ctypes.c_uint64(game_offset), ctypes.c_uint64(first_episode),
         ctypes.c_int32(n_episodes), _p(inj_u), _p(inj_choice), _p(inj_noise_u), _p(inj_noise_a),
-        _p(g_r), _p(g_a), _p(m_r), _p(m_a), _p(tr_a), _p(tr_p))
+        _p(g_r), _p(g_a), _p(m_r), _p(m_a), _p(tr_a), _p(tr_p),
+        *[_p(None if sweep is None else sweep.get(k)) for k in
+          ("gamma", "alpha", "eps_end", "eps_step", "eps", "noise_prob")])
     if rc != 0:
         raise RuntimeError("oracle_episodes failed rc=%d" % rc)
     return dict(game_reward_log=g_r, game_action_log=g_a, reward_log=m_r, action_log=m_a,

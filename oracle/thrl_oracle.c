@@ -266,7 +266,10 @@ int oracle_episodes(const thrl_cfg* c, void* q, int32_t* counter, double* state,
                     double* game_reward_log, double* game_action_log,
                     double* mean_reward_log, double* mean_action_log,
                     int32_t* trace_actions /* [E][T][N][G] or NULL */,
-                    double* trace_price /* [E][T][G] or NULL */) {
+                    double* trace_price /* [E][T][G] or NULL */,
+                    /* per-game sweeps, [N][G] (noise_prob [G]); NULL = the config's scalar */
+                    const double* sw_gamma, const double* sw_alpha, const double* sw_eps_end,
+                    const double* sw_eps_step, double* sw_eps, const double* sw_noise_prob) {
     const int G = c->n_games, N = c->n_agents, T = c->max_steps;
     const size_t stride = oracle_table_stride(c);
     size_t off[THRL_MAXA];
@@ -286,7 +289,8 @@ int oracle_episodes(const thrl_cfg* c, void* q, int32_t* counter, double* state,
         const uint64_t gid = game_offset + (uint64_t)g;
         double eps_g[THRL_MAXA];
         int32_t cnt[THRL_MAXA];
-        for (int i = 0; i < N; i++) { eps_g[i] = eps[i]; cnt[i] = mem_count[i]; }
+        for (int i = 0; i < N; i++) { eps_g[i] = sw_eps ? sw_eps[(size_t)i * G + g] : eps[i]; cnt[i] = mem_count[i]; }
+        const double noise_prob_g = sw_noise_prob ? sw_noise_prob[g] : c->noise_prob;
         double price = state[g];
         for (int e = 0; e < n_episodes; e++) {
             const uint32_t eg = (uint32_t)(first_episode + (uint64_t)e);
@@ -333,7 +337,7 @@ int oracle_episodes(const thrl_cfg* c, void* q, int32_t* counter, double* state,
                         double lo = c->env_a * 0.7;
                         na = lo + (c->env_a - lo) * u01_32(x[1]);
                     }
-                    if (nu < c->noise_prob) { noisy = 1; new_a = na; }
+                    if (nu < noise_prob_g) { noisy = 1; new_a = na; }
                 }
                 double next_price;
                 oracle_env_step(c, scaled, noisy, new_a, &next_price, rew);
@@ -372,15 +376,18 @@ int oracle_episodes(const thrl_cfg* c, void* q, int32_t* counter, double* state,
                     }
                     size_t base = (size_t)g * stride + off[i];
                     int32_t* cn = counter ? counter + base : NULL;
+                    const double alpha_g = sw_alpha ? sw_alpha[(size_t)i * G + g] : c->alpha[i];
+                    const double gamma_g = sw_gamma ? sw_gamma[(size_t)i * G + g] : c->gamma[i];
                     if (c->q_dtype == 1)
                         oracle_td_update_f64((double*)q + base, cn, c->n_actions[i], len, tmp_s, tmp_a,
-                                             tmp_r, tmp_ns, c->alpha[i], c->gamma[i]);
+                                             tmp_r, tmp_ns, alpha_g, gamma_g);
                     else
                         oracle_td_update_f32((float*)q + base, cn, c->n_actions[i], len, tmp_s, tmp_a,
-                                             tmp_r, tmp_ns, c->alpha[i], c->gamma[i]);
+                                             tmp_r, tmp_ns, alpha_g, gamma_g);
                     cnt[i] = 0;                                         /* memory.empty() */
                 }
-                eps_g[i] = oracle_eps_decay(eps_g[i], c->eps_end[i], c->eps_step[i]);
+                eps_g[i] = oracle_eps_decay(eps_g[i], sw_eps_end ? sw_eps_end[(size_t)i * G + g] : c->eps_end[i],
+                                            sw_eps_step ? sw_eps_step[(size_t)i * G + g] : c->eps_step[i]);
             }
             for (int i = 0; i < N; i++) {
                 size_t k = ((size_t)e * N + i) * G + g;
@@ -391,6 +398,7 @@ int oracle_episodes(const thrl_cfg* c, void* q, int32_t* counter, double* state,
             }
         }
         state[g] = price;
+        if (sw_eps) for (int i = 0; i < N; i++) sw_eps[(size_t)i * G + g] = eps_g[i];
         if (g == G - 1) {
             for (int i = 0; i < N; i++) { count_after[i] = cnt[i]; }
             for (int i = 0; i < N; i++) eps[i] = eps_g[i];

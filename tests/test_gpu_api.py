@@ -138,6 +138,31 @@ def test_train_one_resume(tmp_path):
     np.testing.assert_allclose(lf[3:], ls, rtol=1e-12)
 
 
+def test_train_one_sweep(tmp_path):
+    """A gamma sweep (the reference's configs2.json value 0.35 vs example_config's 0.95) as one
+    batched train_one: game g equals a plain run whose config has that gamma."""
+    import torch
+    from th_rl_amd import trainer
+    from th_rl_amd.batched import GameBatch
+    gam = [0.35] * 40 + [0.95] * 40
+    cfg = _config(4, seed=9, n_games=80, print_freq=500, sweep={"gamma": gam})
+    (tmp_path / "s.json").write_text(json.dumps(cfg))
+    trainer.train_one(str(tmp_path / "s"), str(tmp_path / "s.json"))
+    b = torch.load(tmp_path / "s" / "batch.pt", weights_only=True)
+    assert b["sweep"]["gamma"].shape == (2, 80)
+    for gamma, sl in ((0.35, slice(0, 40)), (0.95, slice(40, 80))):
+        c2 = _config(4)
+        for a in c2["agents"]:
+            a["gamma"] = gamma
+        # the initial tables depend on gamma only through QTable's 12.5/(1-gamma) offset: compare a run
+        # started from the sweep run's own initial tables
+        init = GameBatch({"agents": cfg["agents"], "environment": cfg["environment"]}, n_games=80, seed=9).init_tables()
+        ref = GameBatch(c2, n_games=80, seed=9)
+        ref.set_tables(init.tables_numpy(), init.states_numpy())
+        ref.run(4)
+        assert np.array_equal(ref.tables_numpy()[sl], b["q"].numpy()[sl])
+
+
 def test_train_one_rejects_unbuilt_neural_agents(tmp_path):
     from th_rl_amd import trainer
     cfgp = tmp_path / "cfg.json"

@@ -317,6 +317,44 @@ def test_zero_episodes_and_odd_sizes():
     assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
 
 
+def test_per_game_sweeps_vs_oracle():
+    """Per-game gamma / alpha / epsilon schedule / noise_prob (the reference's sweep use case,
+    main.py:13-21 with configs2.json's gamma=0.35, alpha=0.5, epsilon=0.8) on the wave kernel:
+    every game bit-identical to the oracle run with the same per-game arrays, over two calls."""
+    G, E = 97, 6
+    rs = np.random.RandomState(3)
+    config = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV, noise_prob=0.2)}
+    sweep = dict(gamma=rs.choice([0.35, 0.9, 0.95, 0.995], (2, G)), alpha=rs.choice([0.05, 0.1, 0.5], (2, G)),
+                 eps=rs.choice([0.2, 0.5, 0.8], (2, G)), eps_end=rs.choice([0.001, 0.02], (2, G)),
+                 eps_step=rs.choice([0.9995, 0.99], (2, G)), noise_prob=rs.choice([0.0, 0.05, 0.2], G))
+    gb = _batch(config, G, dtype="float32", kernel="wave", seed=21)
+    gb.set_sweep(sweep)
+    gb.init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    o1 = gb.run(E); o2 = gb.run(3)
+    assert o1["kernel"] == "wave"
+    cfg, eps = O.cfg_from_config(config, G, 0)
+    q = q0.copy(); c = np.zeros(q.shape, np.int32); s = s0.copy(); mem = O.Memory(cfg)
+    osw = {k: np.ascontiguousarray(np.asarray(v, np.float64)) for k, v in sweep.items()}
+    oo1 = O.episodes(cfg, q, c, s, eps, mem, E, seed=21, sweep=osw)
+    oo2 = O.episodes(cfg, q, c, s, eps, mem, 3, seed=21, first_episode=E, sweep=osw)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    assert np.array_equal(gb.sweep["eps"].cpu().numpy(), osw["eps"])          # per-game epsilon after 9 episodes
+    np.testing.assert_allclose(o2["reward_log"], oo2["reward_log"], rtol=1e-12)
+    # a sweep whose arrays all equal the config's scalars is the plain run
+    plain = _batch(CFG, 33, kernel="wave", seed=2).init_tables(); plain.run(4)
+    same = _batch(CFG, 33, kernel="wave", seed=2)
+    same.set_sweep(dict(gamma=np.full(33, 0.95), alpha=np.full((2, 33), 0.1), eps_end=np.full(33, 0.001),
+                        eps_step=np.full(33, 0.9995)))
+    same.init_tables(); same.run(4)
+    assert np.array_equal(plain.tables_numpy(), same.tables_numpy())
+    from th_rl_amd._lib import ThrlError
+    gen = _batch(CFG, 8, kernel="generic", seed=2); gen.set_sweep(dict(gamma=np.full(8, 0.9))); gen.init_tables()
+    with pytest.raises(ThrlError, match="wave kernel only"):
+        gen.run(1)
+
+
 def test_learning_outcome_matches_reference_statistics():
     """Statistical parity in Philox mode: the reference's seeded 10,000-epoch
     2xQTable run ends at reward ~ 12.1-12.2 and scaled action ~ 0.29 per agent (above the Nash

@@ -41,6 +41,9 @@ class Buffers(ctypes.Structure):
         ("inj_u", ctypes.c_void_p), ("inj_choice", ctypes.c_void_p),
         ("inj_noise_u", ctypes.c_void_p), ("inj_noise_a", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("sweep_gamma", ctypes.c_void_p), ("sweep_alpha", ctypes.c_void_p),
+        ("sweep_eps_end", ctypes.c_void_p), ("sweep_eps_step", ctypes.c_void_p),
+        ("sweep_eps", ctypes.c_void_p), ("sweep_noise_prob", ctypes.c_void_p),
     ]
 
 

@@ -36,7 +36,7 @@ def _require_gpu(device):
 
 class GameBatch:
     def __init__(self, config, n_games=1, device="cuda:0", dtype="float32", seed=0, game_offset=0,
-                 kernel="auto", counters=True):
+                 kernel="auto", counters=True, sweep=None):
         self.L = _lib.load()
         torch = _torch()
         self.device = _require_gpu(device)
@@ -64,6 +64,31 @@ class GameBatch:
             self.workspace = torch.empty((ws,), dtype=torch.uint8, device=self.device)
         self.replay_mem = None
         self.initialized = False
+        self.sweep = {}
+        if sweep:
+            self.set_sweep(sweep)
+
+    # ------------------------------------------------------------------ sweeps
+    SWEEP_KEYS = ("gamma", "alpha", "eps_end", "eps_step", "eps", "noise_prob")
+
+    def set_sweep(self, sweep):
+        """Per-game hyper-parameters: dict of arrays [N, G] (or [G]: same for every agent) for
+        gamma / alpha / eps_end / eps_step / eps (starting epsilon), and [G] for noise_prob.
+        Keys that are absent keep the config's scalar for every game."""
+        torch = _torch()
+        for k, v in sweep.items():
+            if k not in self.SWEEP_KEYS:
+                raise ThrlError("unknown sweep key %r (known: %s)" % (k, ", ".join(self.SWEEP_KEYS)))
+            a = np.asarray(v, np.float64)
+            if k == "noise_prob":
+                a = a.reshape(self.G)
+            else:
+                a = np.broadcast_to(a.reshape(-1, self.G), (self.N, self.G)).copy()
+            self.sweep[k] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if ("eps_end" in self.sweep or "eps_step" in self.sweep) and "eps" not in self.sweep:
+            start = np.repeat(np.asarray(self.eps, np.float64)[:, None], self.G, axis=1)
+            self.sweep["eps"] = torch.from_numpy(start).to(self.device)
+        return self
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -160,6 +185,8 @@ class GameBatch:
             if self.replay_mem is not None:
                 b.replay_mem, b.replay_mem_bytes = self._ptr(self.replay_mem), self.replay_mem.numel()
             b.workspace, b.workspace_bytes = self._ptr(self.workspace), self.workspace.numel()
+            for k in self.SWEEP_KEYS:
+                setattr(b, "sweep_" + k, self._ptr(self.sweep.get(k)))
             r = _lib.Run()
             r.seed, r.game_offset, r.first_episode = self.seed, self.game_offset, self.episode
             r.n_episodes, r.kernel = E, self.kernel
@@ -213,7 +240,8 @@ class GameBatch:
                 "mem_count": [int(x) for x in self.mem_count], "seed": int(self.seed),
                 "game_offset": int(self.game_offset), "dtype": int(self.dtype), "n_games": int(self.G),
                 "offsets": list(self.offsets), "shapes": [list(x) for x in self.shapes],
-                "replay_mem": None if self.replay_mem is None else self.replay_mem.cpu()}
+                "replay_mem": None if self.replay_mem is None else self.replay_mem.cpu(),
+                "sweep": {k: v.cpu() for k, v in self.sweep.items()}}
 
     def save(self, path):
         _torch().save(self.state_dict(), path)
@@ -234,6 +262,8 @@ class GameBatch:
         self.episode = int(sd["episode"])
         self.mem_count = [int(x) for x in sd["mem_count"]]
         self.seed, self.game_offset = int(sd["seed"]), int(sd["game_offset"])
+        for k, v in (sd.get("sweep") or {}).items():
+            self.sweep[k] = v.to(self.device)
         if sd.get("replay_mem") is not None:
             self._ensure_replay_mem()
             self.replay_mem.copy_(sd["replay_mem"])

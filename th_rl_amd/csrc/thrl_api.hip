@@ -262,6 +262,8 @@ int thrl_qtable_init(const thrl_cfg* c, void* q, int32_t* counter, double* state
 }
 
 static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, hipStream_t s) {
+    if (b->sweep_gamma || b->sweep_alpha || b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob)
+        return fail(THRL_ERR_UNSUPPORTED, "per-game sweeps run on the fused wave kernel only (this config/request needs the generic kernel)");
     const int capmax = capmax_of(c);
     const size_t need = thrl_replay_mem_bytes(c);
     if (!b->replay_mem || b->replay_mem_bytes < need)
@@ -344,6 +346,12 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     a.partial = (double*)((char*)b->workspace + kLutRegion);
     a.tlog = (uint32_t*)((char*)b->workspace + kLutRegion + kMaxWaves * 64 * sizeof(double));
     a.seed = run->seed; a.game_offset = run->game_offset;
+    a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
+    a.sw_eps_step = b->sweep_eps_step; a.sw_eps = b->sweep_eps; a.sw_noise_prob = b->sweep_noise_prob;
+    if ((b->sweep_eps_end || b->sweep_eps_step) && !b->sweep_eps)
+        return fail(THRL_ERR_NULL, "sweep_eps_end / sweep_eps_step need the per-game epsilon state sweep_eps");
+    if (b->sweep_noise_prob && !(c->noise_prob > 0.0))
+        return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it sizes the row window)");
 
     const int block = p.waves_per_block * 64;
     int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;

@@ -61,6 +61,9 @@ struct WaveArgs {
     const int8_t* inj_choice;       // parity mode: device [n_episodes][T][2][G] random.choice indices
     const double* inj_noise_u;      // parity mode with noise: device [n_episodes][T][G]
     const double* inj_noise_a;
+    // per-game sweeps (null = the scalar parameters above), [2][G] except noise_prob [G]
+    const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
+    double* sw_eps; const double* sw_noise_prob;
     uint64_t seed, game_offset, first_episode;
     double eps[kWaveMaxEpisodes][2];
 };

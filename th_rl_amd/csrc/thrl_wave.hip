@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
 // SIMD: keep the register allocation at <= 96 VGPRs there (NSEG <= 2).
 // NOISE: environment noise (environments.py:28-31) handled per step (price not on the LUT);
 // its larger row window leaves room for fewer waves, so the register budget is relaxed.
-template <int NSEG, int NRSEG, bool NOISE>
+// SWEEP: per-game hyper-parameter arrays (thrl_buffers.sweep_*); compiled only together with NOISE
+// so the headline variant carries none of that state.
+template <int NSEG, int NRSEG, bool NOISE, bool SWEEP>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NOISE ? 3 : (NSEG <= 2 ? 5 : 4))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -209,8 +211,6 @@ k_wave_episodes(const WaveArgs a) {
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
     const double inv_T_den = (double)T;
-    const float gamma_h = half ? p1.gamma_f : p0.gamma_f;
-    const float alpha_h = half ? p1.alpha_f : p0.alpha_f;
 
     double acc = 0.0;   // lane (e*4+k): sum over this wave's games of episode-e log value k
     const int wave_gid = blockIdx.x * a.waves_per_block + wib;
@@ -219,6 +219,25 @@ k_wave_episodes(const WaveArgs a) {
         const uint64_t gid = a.game_offset + (uint64_t)g;
         float* __restrict__ q0 = a.q + (int64_t)g * a.stride + p0.table_off;
         float* __restrict__ q1 = a.q + (int64_t)g * a.stride + p1.table_off;
+
+        // ---- per-game hyper-parameters (sweeps) or the config's scalars
+        float gamma_h = half ? p1.gamma_f : p0.gamma_f;
+        float alpha_h = half ? p1.alpha_f : p0.alpha_f;
+        float oma0 = p0.one_minus_alpha_f, oma1 = p1.one_minus_alpha_f;
+        if (SWEEP && a.sw_gamma) gamma_h = (float)a.sw_gamma[(size_t)half * a.G + g];
+        if (SWEEP && a.sw_alpha) {
+            alpha_h = (float)a.sw_alpha[(size_t)half * a.G + g];
+            oma0 = (float)__dsub_rn(1.0, a.sw_alpha[g]);
+            oma1 = (float)__dsub_rn(1.0, a.sw_alpha[(size_t)a.G + g]);
+        }
+        double epsg0 = 0.0, epsg1 = 0.0;               // per-game epsilon (sweep mode)
+        const bool sw_eps_on = SWEEP && a.sw_eps != nullptr;
+        if (sw_eps_on) { epsg0 = a.sw_eps[g]; epsg1 = a.sw_eps[(size_t)a.G + g]; }
+        const double eend0 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[g] : p0.eps_end;
+        const double eend1 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[(size_t)a.G + g] : p1.eps_end;
+        const double estep0 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[g] : p0.eps_step;
+        const double estep1 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[(size_t)a.G + g] : p1.eps_step;
+        const double noise_prob_g = (SWEEP && a.sw_noise_prob) ? a.sw_noise_prob[g] : a.env.noise_prob;
 
         // ---- initial state -> local rows (window or spill)
         const double price0 = a.state[g];
@@ -267,7 +286,7 @@ k_wave_episodes(const WaveArgs a) {
         double last_price = price0;
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
-            const double eps0 = a.eps[e][0], eps1 = a.eps[e][1];
+            const double eps0 = sw_eps_on ? epsg0 : a.eps[e][0], eps1 = sw_eps_on ? epsg1 : a.eps[e][1];
 
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
             //          during play: agents.py only writes it in train_net), and the
@@ -328,7 +347,7 @@ k_wave_episodes(const WaveArgs a) {
                         nu = u01_32(xn.x);
                         na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
                     }
-                    if (nu < a.env.noise_prob) rw |= 4u;
+                    if (nu < noise_prob_g) rw |= 4u;
                     nav[seg] = na;
                 }
                 rwv[seg] = rw;
@@ -429,8 +448,8 @@ k_wave_episodes(const WaveArgs a) {
                 if (!valid) { a0 = 0; a1 = 0; srow = 0; }
                 const float ov0 = tab0[srow * A + a0];
                 const float ov1 = tab1[srow * A + a1];
-                t4q[seg] = pack_halves(__builtin_bit_cast(unsigned, __fmul_rn(p0.one_minus_alpha_f, ov0)),
-                                       __builtin_bit_cast(unsigned, __fmul_rn(p1.one_minus_alpha_f, ov1)));
+                t4q[seg] = pack_halves(__builtin_bit_cast(unsigned, __fmul_rn(oma0, ov0)),
+                                       __builtin_bit_cast(unsigned, __fmul_rn(oma1, ov1)));
                 act[seg] = a0 | (a1 << 8) | (srow << 16) | (ns << 24);
             }
             __builtin_amdgcn_wave_barrier();
@@ -521,6 +540,11 @@ k_wave_episodes(const WaveArgs a) {
                 if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
                 if ((lane >> 2) == e) acc += v;
             }
+            // epsilon decays after every train_net call (agents.py:78)
+            if (SWEEP) {
+                epsg0 = __dadd_rn(eend0, __dmul_rn(__dsub_rn(epsg0, eend0), estep0));
+                epsg1 = __dadd_rn(eend1, __dmul_rn(__dsub_rn(epsg1, eend1), estep1));
+            }
         }
 
         // ---- stream the windows back LDS -> HBM, store the env state
@@ -538,6 +562,7 @@ k_wave_episodes(const WaveArgs a) {
                 q1[spill1 * A + lane] = tab1[(W + 1) * A + lane];
             }
             if (lane == 0 && a.n_episodes > 0) a.state[g] = last_price;
+            if (lane == 0 && sw_eps_on) { a.sw_eps[g] = epsg0; a.sw_eps[(size_t)a.G + g] = epsg1; }
         }
         __builtin_amdgcn_wave_barrier();
 
@@ -635,9 +660,9 @@ __global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int 
     }
 }
 
-template <int NSEG, int NRSEG, bool NOISE>
+template <int NSEG, int NRSEG, bool NOISE, bool SWEEP>
 static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((k_wave_episodes<NSEG, NRSEG, NOISE>), dim3(grid), dim3(block), lds, s, a);
+    hipLaunchKernelGGL((k_wave_episodes<NSEG, NRSEG, NOISE, SWEEP>), dim3(grid), dim3(block), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -647,31 +672,33 @@ int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <bool NOISE>
+template <bool NOISE, bool SWEEP>
 static int launch_wave_n(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
     const int nrseg = (a.win_rows + 2 + 63) / 64;
     if (nrseg == 1) {
         switch (nseg) {
-            case 1: return launch_wave_t<1, 1, NOISE>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<2, 1, NOISE>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<3, 1, NOISE>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<4, 1, NOISE>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<1, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 1, NOISE, SWEEP>(a, grid, block, lds, s);
         }
     } else if (nrseg == 2) {
         switch (nseg) {
-            case 1: return launch_wave_t<1, 2, NOISE>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<2, 2, NOISE>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<3, 2, NOISE>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<4, 2, NOISE>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<1, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<2, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<3, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<4, 2, NOISE, SWEEP>(a, grid, block, lds, s);
         }
     }
     return -1;
 }
 
 int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    return a.env.noise_prob > 0.0 ? launch_wave_n<true>(a, grid, block, lds, s)
-                                  : launch_wave_n<false>(a, grid, block, lds, s);
+    const bool sweep = a.sw_gamma || a.sw_alpha || a.sw_eps_end || a.sw_eps_step || a.sw_eps || a.sw_noise_prob;
+    if (sweep) return launch_wave_n<true, true>(a, grid, block, lds, s);      // noise code present, taken per game
+    return a.env.noise_prob > 0.0 ? launch_wave_n<true, false>(a, grid, block, lds, s)
+                                  : launch_wave_n<false, false>(a, grid, block, lds, s);
 }
 
 int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,

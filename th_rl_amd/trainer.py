@@ -10,7 +10,10 @@ kernels).  The JSON schema is the reference's; the optional extra keys in the
                  "seed": null,        # Philox seed (null: drawn from numpy's global RNG)
                  "dtype": null,       # "float64" | "float32" (default f64 for 1 game, f32 otherwise)
                  "device": "cuda:0", "game_offset": 0, "kernel": "auto",
-                 "resume": null}     # path of a batch.pt written by an earlier run: continue it
+                 "resume": null,     # path of a batch.pt written by an earlier run: continue it
+                 "sweep": null}      # per-game hyper-parameters, e.g. {"gamma": [0.35, 0.95, ...]}: arrays of
+                                     # length n_games (or [agent][game]) for gamma / alpha / eps / eps_end /
+                                     # eps_step / noise_prob -- a config sweep as ONE batched run
 
 n_games == 1: tables come from the constructed agents (numpy's global RNG, exactly where
 the reference draws them) and the run is float64.  n_games > 1: every game's tables and
@@ -76,7 +79,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     if all_tabular:
         batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
                           seed=seed, game_offset=int(training.get("game_offset", 0)),
-                          kernel=training.get("kernel", "auto"))
+                          kernel=training.get("kernel", "auto"), sweep=training.get("sweep", None))
     else:
         # games with neural agents: the unfused batched operator loop (mixed.py)
         from th_rl_amd.mixed import MixedGameBatch
