@@ -138,6 +138,30 @@ def test_train_one_resume(tmp_path):
     np.testing.assert_allclose(lf[3:], ls, rtol=1e-12)
 
 
+def test_sharded_launch_equals_single_process(tmp_path):
+    """th_rl_amd.launch with 2 ranks (both mapped onto this box's one GPU): every game and the merged
+    log equal a single-process run of all games -- the seed-sharded multi-GPU path."""
+    import pandas
+    import torch
+    from th_rl_amd import trainer
+    from th_rl_amd.launch import launch
+    cfg = _config(6, seed=17, n_games=101, print_freq=500)          # uneven split: 51 + 50
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    trainer.train_one(str(tmp_path / "one"), str(tmp_path / "c.json"))
+    launch(str(tmp_path / "c.json"), str(tmp_path / "two"), gpus=2)
+    one = torch.load(tmp_path / "one" / "batch.pt", weights_only=True)
+    s0 = torch.load(tmp_path / "two" / "shard0" / "batch.pt", weights_only=True)
+    s1 = torch.load(tmp_path / "two" / "shard1" / "batch.pt", weights_only=True)
+    assert s0["q"].shape[0] == 51 and s1["q"].shape[0] == 50 and s1["game_offset"] == 51
+    assert torch.equal(torch.cat([s0["q"], s1["q"]]), one["q"])
+    assert torch.equal(torch.cat([s0["counter"], s1["counter"]]), one["counter"])
+    for f in ("0.npy", "1.npy", "0_counter.npy", "config.json"):
+        assert open(tmp_path / "two" / f, "rb").read() == open(tmp_path / "one" / f, "rb").read(), f
+    l1 = pandas.read_csv(tmp_path / "one" / "log.csv", header=[0, 1]).to_numpy()
+    l2 = pandas.read_csv(tmp_path / "two" / "log.csv", header=[0, 1]).to_numpy()
+    np.testing.assert_allclose(l2, l1, rtol=1e-12)
+
+
 def test_train_one_sweep(tmp_path):
     """A gamma sweep (the reference's configs2.json value 0.35 vs example_config's 0.95) as one
     batched train_one: game g equals a plain run whose config has that gamma."""
