@@ -68,26 +68,31 @@ def cpu_baseline(seconds_target=10.0):
 
 
 def bench_nn(args):
-    """BASELINE configs[3]: 2 Reinforce agents (agents.py:119-220) x 65,536 games, unfused operator
-    loop (mixed.MixedGameBatch).  steps = episodes; the policy trains every 10 episodes."""
+    """BASELINE configs[3]: 2 Reinforce agents (agents.py:119-220) x 65,536 games through
+    mixed.MixedGameBatch (--nn-loop fused: thrl_mixed_episodes; unfused: one launch per reference
+    call).  --nn-agents qr = the reference's shipped pairing, QTable vs Reinforce.
+    steps = episodes; the policy trains every 10 episodes."""
     import torch
     from th_rl_amd.mixed import MixedGameBatch
     G = args.games if args.games != (1 << 20) else 65536
     ag = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
-    config = {"agents": [dict(ag), dict(ag)], "environment": dict(CFG["environment"])}
+    first = dict(CFG["agents"][0]) if args.nn_agents == "qr" else dict(ag)
+    config = {"agents": [first, dict(ag)], "environment": dict(CFG["environment"])}
+    fused = args.nn_loop == "fused"
     mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=0).init_tables()
-    mb.run(args.warmup)
+    mb.run(args.warmup, fused=fused)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mb.run(args.steps)
+    mb.run(args.steps, fused=fused)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "env-steps/sec, 2-agent neural policy (Reinforce) x %d games" % G,
+    who = "QTable vs Reinforce" if args.nn_agents == "qr" else "2-agent Reinforce"
+    print(json.dumps({"metric": "env-steps/sec, %s (neural policy) x %d games" % (who, G),
                       "value": G * T_STEPS * args.steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                       "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-                      "config": {"workload": "2-agent Reinforce x %d games, unfused operator loop, MFMA off" % G,
-                                 "network_updates": mb.nn[0].step}}))
+                      "config": {"workload": "%s x %d games, %s loop, MFMA off" % (who, G, args.nn_loop),
+                                 "network_updates": mb.nn[1].step}}))
 
 
 def main():
@@ -97,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--games", type=int, default=1 << 20, help="games per GPU")
     ap.add_argument("--chunk", type=int, default=10, help="episodes per kernel launch (<=16)")
+    ap.add_argument("--nn-loop", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--nn-agents", default="rr", choices=["rr", "qr"])
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
     ap.add_argument("--workload", default="qtable", choices=["qtable", "nn"],
                     help="qtable = the headline metric (default); nn = BASELINE configs[3]: 2 Reinforce "

@@ -221,6 +221,28 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
                             int32_t step, int32_t n, const double* price, const int32_t* action,
                             const double* reward, double gamma, double entropy_coef, double lr,
                             float* grad_out, void* stream);
+/*
+ * Fused episodes for games whose agents are any mix of QTable and Reinforce (the pairing of the
+ * reference's example configs): trainer.train_one's loop (trainer.py:46-70) with QTable.train_net
+ * inside the kernel.  Reinforce transitions go to that agent's replay buffer; the CALLER runs
+ * thrl_nn_reinforce_train when len(memory) >= min_memory and must size n_episodes so that no
+ * network update falls inside one call.  Replay buffers are rings [buf_len][G] per agent.
+ */
+typedef struct {
+    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce                        */
+    const float* nn_params[THRL_MAXA];   /* device [G][P] for Reinforce agents               */
+    double*  buf_price[THRL_MAXA];       /* device [buf_len][G] state  (trainer.py:62)       */
+    int32_t* buf_action[THRL_MAXA];
+    double*  buf_reward[THRL_MAXA];
+    double*  buf_nprice[THRL_MAXA];      /* next state                                       */
+    double*  buf_scratch[THRL_MAXA];     /* QTable agents: old_value snapshot (agents.py:67) */
+    int32_t  buf_len[THRL_MAXA];
+    int32_t  min_memory[THRL_MAXA];
+    int32_t  count[THRL_MAXA];           /* in/out: appends since the last memory.empty()    */
+} thrl_mixed;
+int thrl_mixed_episodes(const thrl_cfg* cfg, thrl_mixed* mx, void* q, int32_t* counter, double* state,
+                        thrl_run* run, double* game_reward_log, double* game_action_log, void* stream);
+
 /* Philox draws for one lockstep step of a caller-driven loop: u [N][G] f64 uniforms and
  * choice [N][G] int8 indices (agents.py:81-82), optionally the env's two noise draws [G]
  * (environments.py:28-29); same streams/counters as thrl_qtable_episodes uses internally. */

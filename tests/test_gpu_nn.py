@@ -114,8 +114,9 @@ R_AGENT = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "act
 ENV = dict(name="NoisyPriceState", noise_prob=0, a=10, b=1, nplayers=2, max_steps=100)
 
 
+@pytest.mark.parametrize("mixed_fused", [False, True])
 @pytest.mark.parametrize("dtype,noise", [("float32", 0.0), ("float64", 0.05)])
-def test_unfused_operator_loop_equals_fused_kernels(dtype, noise):
+def test_unfused_operator_loop_equals_fused_kernels(dtype, noise, mixed_fused):
     """An all-QTable game run through the unfused operator loop (one launch per reference call)
     gives bit-identical tables / counters / state / per-game logs to the fused kernels."""
     from th_rl_amd.batched import GameBatch
@@ -128,13 +129,44 @@ def test_unfused_operator_loop_equals_fused_kernels(dtype, noise):
     mixed = MixedGameBatch(config, n_games=G, dtype=dtype, seed=5)
     mixed.set_tables(fused.tables_numpy(), fused.states_numpy())
     rf = fused.run(E, per_game_logs=True)
-    rm = mixed.run(E)
+    rm = mixed.run(E, fused=mixed_fused)
     assert np.array_equal(mixed.tables_numpy(), fused.tables_numpy())
     assert np.array_equal(mixed.counters_numpy(), fused.counters_numpy())
     assert np.array_equal(mixed.states_numpy(), fused.states_numpy())
     assert np.array_equal(rm["game_reward_log"], rf["game_reward_log"])
     assert np.array_equal(rm["game_action_log"], rf["game_action_log"])
     assert mixed.eps[:2] == fused.eps[:2]
+
+
+@pytest.mark.parametrize("dtype,noise,order", [("float64", 0.0, "qr"), ("float32", 0.1, "rq"), ("float64", 0.0, "rr")])
+def test_mixed_episode_kernel_equals_operator_loop(dtype, noise, order):
+    """thrl_mixed_episodes (one launch per run of episodes between network updates) against the
+    per-call operator loop on the same seeds: tables, counters, state, per-game logs, network
+    parameters and Adam state after several updates, replay-buffer bookkeeping -- all bit-identical.
+    Covers a ring buffer that wraps (capacity < what an episode appends before training)."""
+    from th_rl_amd.mixed import MixedGameBatch
+    T = 25
+    q = dict(Q_AGENT, min_memory=T, capacity=40)
+    r = dict(R_AGENT, min_memory=60, entropy=0.01)
+    agents = {"qr": [q, r], "rq": [r, dict(q, min_memory=2 * T, capacity=30)], "rr": [r, dict(r, min_memory=T)]}[order]
+    config = {"agents": [dict(a) for a in agents], "environment": dict(ENV, max_steps=T, noise_prob=noise)}
+    G, E = 5, 8
+    a = MixedGameBatch(config, n_games=G, dtype=dtype, seed=21, game_offset=3).init_tables()
+    b = MixedGameBatch(config, n_games=G, dtype=dtype, seed=21, game_offset=3).init_tables()
+    ra = a.run(3, fused=True); ra2 = a.run(E - 3, fused=True)       # split: state carries across calls
+    rb = b.run(E, fused=False)
+    assert ra["kernel"] == "mixed-fused" and rb["kernel"] == "unfused"
+    assert np.array_equal(np.concatenate([ra["game_reward_log"], ra2["game_reward_log"]]), rb["game_reward_log"])
+    assert np.array_equal(np.concatenate([ra["game_action_log"], ra2["game_action_log"]]), rb["game_action_log"])
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy())
+    assert np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy())
+    assert a.eps == b.eps and a.count == b.count and a.episode == b.episode
+    for i in a.nn:
+        assert a.nn[i].step == b.nn[i].step and a.nn[i].step >= 2
+        assert np.array_equal(a.nn[i].params.cpu().numpy(), b.nn[i].params.cpu().numpy())
+        assert np.array_equal(a.nn[i].adam_m.cpu().numpy(), b.nn[i].adam_m.cpu().numpy())
+        assert np.array_equal(a.nn[i].adam_v.cpu().numpy(), b.nn[i].adam_v.cpu().numpy())
 
 
 def test_qtable_vs_reinforce_game_against_composed_oracle():

@@ -57,6 +57,17 @@ class Run(ctypes.Structure):
     ]
 
 
+class Mixed(ctypes.Structure):
+    """thrl_mixed"""
+    _fields_ = [
+        ("kind", ctypes.c_int32 * MAXA), ("nn_params", ctypes.c_void_p * MAXA),
+        ("buf_price", ctypes.c_void_p * MAXA), ("buf_action", ctypes.c_void_p * MAXA),
+        ("buf_reward", ctypes.c_void_p * MAXA), ("buf_nprice", ctypes.c_void_p * MAXA),
+        ("buf_scratch", ctypes.c_void_p * MAXA), ("buf_len", ctypes.c_int32 * MAXA),
+        ("min_memory", ctypes.c_int32 * MAXA), ("count", ctypes.c_int32 * MAXA),
+    ]
+
+
 # every symbol include/thrl.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "thrl_version", "thrl_last_error", "thrl_table_stride", "thrl_table_offset",
@@ -64,6 +75,7 @@ SYMBOLS = [
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
     "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
+    "thrl_mixed_episodes",
 ]
 
 _lib = None
@@ -135,6 +147,8 @@ def load():
                                           dbl, dbl, dbl, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
     L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp]
+    L.thrl_mixed_episodes.restype = ctypes.c_int
+    L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
     if L.thrl_version() != 1:
         raise ThrlError("th_rl_amd: ABI version mismatch (%d)" % L.thrl_version())
     _lib = L

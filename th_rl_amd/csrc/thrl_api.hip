@@ -43,14 +43,6 @@ int h_encode32(double price, const thrl_cfg* c, int i) {
     x = x * (float)c->n_states[i];
     return (int)rintf(x);
 }
-double h_price(const thrl_cfg* c, const double* scaled) {
-    const double ratio = c->env_a / c->env_b;
-    double Q = 0.0;
-    for (int i = 0; i < c->n_agents; i++) Q = Q + ratio * scaled[i];
-    double p = c->env_a - c->env_b * Q;
-    return p > 0.0 ? p : 0.0;
-}
-
 int validate(const thrl_cfg* c) {
     if (!c) return fail(THRL_ERR_NULL, "cfg is NULL");
     if (c->n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", c->n_games);
@@ -555,6 +547,58 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
     const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward,
                                   (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
+}
+
+int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* counter, double* state, thrl_run* run,
+                        double* game_reward_log, double* game_action_log, void* stream) {
+    int rc = validate(c);
+    if (rc) return rc;
+    if (!mx || !q || !state || !run || !game_reward_log || !game_action_log)
+        return fail(THRL_ERR_NULL, "a required pointer is NULL");
+    if (run->n_episodes < 0) return fail(THRL_ERR_BAD_CONFIG, "n_episodes < 0");
+    if (run->n_episodes == 0) return THRL_OK;
+    MixedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.N = c->n_agents; a.T = c->max_steps; a.n_episodes = run->n_episodes;
+    a.stride = (int64_t)thrl_table_stride(c);
+    fill_agents(c, a.ag, &a.env);
+    a.q = q; a.counter = counter; a.state = state;
+    a.game_reward_log = game_reward_log; a.game_action_log = game_action_log;
+    a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
+    for (int i = 0; i < c->n_agents; i++) {
+        if (mx->kind[i] != 0 && mx->kind[i] != 1) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
+        if (mx->kind[i] == 1 && (!mx->nn_params[i] || c->n_actions[i] > 32))
+            return fail(THRL_ERR_NULL, "agent %d: Reinforce needs nn_params and actions <= 32", i);
+        if (mx->buf_len[i] > 0 && (!mx->buf_price[i] || !mx->buf_action[i] || !mx->buf_reward[i] || !mx->buf_nprice[i]))
+            return fail(THRL_ERR_NULL, "agent %d: replay buffer pointers are NULL", i);
+        if (mx->kind[i] == 0 && mx->buf_len[i] > 0 && !mx->buf_scratch[i])
+            return fail(THRL_ERR_NULL, "agent %d: QTable agents need buf_scratch", i);
+        a.kind[i] = mx->kind[i]; a.nn_params[i] = mx->nn_params[i];
+        a.buf_price[i] = mx->buf_price[i]; a.buf_action[i] = mx->buf_action[i]; a.buf_reward[i] = mx->buf_reward[i];
+        a.buf_nprice[i] = mx->buf_nprice[i]; a.buf_ov[i] = mx->buf_scratch[i];
+        a.buf_len[i] = mx->buf_len[i]; a.min_memory[i] = mx->min_memory[i]; a.count0[i] = mx->count[i];
+        a.eps0[i] = run->eps[i];
+    }
+    const char* why = "";
+    if (plan_mixed(a, c->q_dtype, &why)) return fail(THRL_ERR_UNSUPPORTED, "thrl_mixed_episodes: %s", why);
+    const int e = launch_mixed(a, c->q_dtype, (hipStream_t)stream);
+    if (e) return hip_fail(e, "k_mixed_episodes launch");
+    // host mirror of the bookkeeping that is identical for every game
+    for (int ep = 0; ep < run->n_episodes; ep++)
+        for (int i = 0; i < c->n_agents; i++) {
+            const int cap = mx->buf_len[i];
+            if (cap > 0)
+                for (int t = 0; t < c->max_steps; t++) {
+                    mx->count[i] += 1;
+                    if (mx->count[i] >= 2 * cap) mx->count[i] -= cap;
+                }
+            if (mx->kind[i] == 0) {
+                const int len = mx->count[i] < cap ? mx->count[i] : cap;
+                if (cap > 0 && len >= mx->min_memory[i]) mx->count[i] = 0;
+                run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];
+            }
+        }
+    return THRL_OK;
 }
 
 int thrl_op_draws(const thrl_cfg* c, uint64_t seed, uint64_t game_offset, uint64_t episode, int32_t step,

@@ -116,6 +116,27 @@ int launch_op_encode(const OpArgs& a, hipStream_t s);
 int launch_op_td(const OpArgs& a, int q_dtype, hipStream_t s);
 
 // ---- neural policy agent (thrl_nn.hip)
+struct MixedArgs {
+    int32_t G, N, T, n_episodes;
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[THRL_MAXA];            // QTable parameters; for a Reinforce slot: n_actions, act_lo, act_span
+    int32_t kind[THRL_MAXA];              // 0 = QTable, 1 = Reinforce
+    void* q; int32_t* counter; double* state;
+    const float* nn_params[THRL_MAXA];    // [G][P] per Reinforce agent
+    double* buf_price[THRL_MAXA]; int32_t* buf_action[THRL_MAXA];      // replay buffers [buf_len][G]
+    double* buf_reward[THRL_MAXA]; double* buf_nprice[THRL_MAXA]; double* buf_ov[THRL_MAXA];
+    int32_t buf_len[THRL_MAXA]; int32_t min_memory[THRL_MAXA]; int32_t count0[THRL_MAXA];
+    double eps0[THRL_MAXA];
+    double* game_reward_log; double* game_action_log;                  // [n_episodes][N][G]
+    uint64_t seed, game_offset, first_episode;
+    int32_t n_r; int32_t ragent[2];                                    // the (at most 2) Reinforce agents
+    int32_t lds_off[THRL_MAXA];                                        // QTable agents: element offset of the table in LDS
+    int32_t lds_bytes;
+};
+// fills n_r / ragent / lds_off / lds_bytes; returns 0 or -1 with a reason when the config does not fit
+int plan_mixed(MixedArgs& a, int q_dtype, const char** why);
+int launch_mixed(const MixedArgs& a, int q_dtype, hipStream_t s);
 int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s);
 int launch_nn_act(int G, int A, const float* params, const double* price, const double* u, int32_t* act,
                   float* prob, hipStream_t s);

@@ -1,0 +1,265 @@
+// thrl_mixed.hip -- fused episodes for games whose agents are any mix of QTable and Reinforce
+// (the pairing of the reference's example configs): trainer.train_one's step loop
+// (trainer.py:46-70) with QTable.train_net (agents.py:59-78) at every episode end, for
+// `n_episodes` per launch.  ONE WAVEFRONT PER GAME:
+//   * each Reinforce network (1 -> 256 -> A) lives in registers for the whole launch
+//     (thrl_policy.h), so the 23.6 KB of weights per agent-game are read from HBM once per
+//     launch instead of once per step;
+//   * QTable tables live in LDS for the launch (row argmax / row max are one lane per action);
+//   * Philox draws are produced 64 steps at a time, one step per lane; the scaled-action tables
+//     and the two log accumulators are lane-parallel, so one float64 division per step remains;
+//   * Reinforce transitions are appended to that agent's HBM replay ring; the host launches
+//     k_nn_reinforce_train when an update is due and sizes n_episodes so none falls inside.
+// Same Philox streams and the same arithmetic as the unfused operator loop: bit-identical.
+#include "thrl_policy.h"
+#include "thrl_kernels.h"
+
+namespace thrl {
+namespace {
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float lane_val(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_val(double v, int l) { return lane_f64(v, l); }
+
+template <typename T> __device__ __forceinline__ T neg_inf();
+template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
+template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
+
+template <typename T, int NR, int APAD>
+__global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
+    T* const lds = reinterpret_cast<T*>(smem_mx);
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int N = a.N, G = a.G, Tn = a.T;
+    const uint64_t gid = a.game_offset + (uint64_t)g;
+    T* __restrict__ qg = reinterpret_cast<T*>(a.q) + (int64_t)g * a.stride;
+    int32_t* __restrict__ cg = a.counter ? a.counter + (int64_t)g * a.stride : nullptr;
+
+    // ---- launch prologue: tables -> LDS, networks -> registers, per-lane scale tables
+    PolicyRegs<APAD> net0, net1;
+    double sc_tab[THRL_MAXA];
+#pragma unroll
+    for (int i = 0; i < THRL_MAXA; i++) {
+        sc_tab[i] = 0.0;
+        if (i >= N) continue;
+        const AgentParams& p = a.ag[i];
+        if (a.kind[i] == 0) {
+            const int n = p.rows * p.n_actions;
+            for (int e = lane; e < n; e += 64) lds[a.lds_off[i] + e] = qg[p.table_off + e];
+            sc_tab[i] = scale_action(lane, p);
+        } else {
+            // Reinforce.scale (agents.py:153-157): action / actions * (hi - lo) + lo
+            sc_tab[i] = __dadd_rn(__dmul_rn(__ddiv_rn((double)lane, (double)p.n_actions), p.act_span), p.act_lo);
+        }
+    }
+    if (NR >= 1) {
+        const int A = a.ag[a.ragent[0]].n_actions;
+        policy_load(net0, a.nn_params[a.ragent[0]] + (int64_t)g * (2 * kH + A * kH + A), A, lane);
+    }
+    if (NR >= 2) {
+        const int A = a.ag[a.ragent[1]].n_actions;
+        policy_load(net1, a.nn_params[a.ragent[1]] + (int64_t)g * (2 * kH + A * kH + A), A, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    double price = a.state[g];
+    double eps[THRL_MAXA];
+    int cnt[THRL_MAXA];
+#pragma unroll
+    for (int i = 0; i < THRL_MAXA; i++) { eps[i] = a.eps0[i]; cnt[i] = a.count0[i]; }
+    const bool noisy = a.env.noise_prob > 0.0;
+    const double Td = (double)Tn;
+
+    for (int e = 0; e < a.n_episodes; e++) {
+        const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
+        double acc = 0.0;                          // lane i: reward log of agent i ; lane 32+i: action log
+        u32x4 xs[THRL_MAXA / 2];
+        u32x4 xn = {0, 0, 0, 0};
+        for (int t = 0; t < Tn; t++) {
+            const int tl = t & 63;
+            if (tl == 0) {                         // draws for steps t .. t+63, one step per lane
+#pragma unroll
+                for (int pr = 0; pr < THRL_MAXA / 2; pr++)
+                    if (2 * pr < N) xs[pr] = draw(a.seed, gid, eg, (uint32_t)(t + lane), (uint32_t)pr);
+                if (noisy) xn = draw(a.seed, gid, eg, (uint32_t)(t + lane), kStreamNoise);
+            }
+            double scaled[THRL_MAXA], rew[THRL_MAXA];
+            int act[THRL_MAXA];
+#pragma unroll
+            for (int i = 0; i < THRL_MAXA; i++) {
+                scaled[i] = 0.0; act[i] = 0;
+                if (i >= N) continue;
+                const AgentParams& p = a.ag[i];
+                const u32x4& x = xs[i >> 1];
+                const uint32_t xu = lane_u32((i & 1) ? x.z : x.x, tl), xc = lane_u32((i & 1) ? x.w : x.y, tl);
+                const double u = u01_32(xu);
+                int aa;
+                if (a.kind[i] == 0) {                                   // QTable.sample_action (agents.py:80-89)
+                    if (u < eps[i]) {
+                        aa = (int)__umulhi(xc, (uint32_t)p.n_actions);
+                    } else {
+                        const int row = encode32(price, p);
+                        const T v = lane < p.n_actions ? lds[a.lds_off[i] + row * p.n_actions + lane] : neg_inf<T>();
+                        const T m = wave_allmax(v);
+                        aa = (int)__builtin_ctzll(__ballot(v == m && lane < p.n_actions));   // first max wins
+                    }
+                } else if (NR >= 1 && i == a.ragent[0]) {               // Reinforce.sample_action (agents.py:159-163)
+                    aa = policy_act(net0, p.n_actions, (float)price, true, (float)u, lane, (float*)nullptr);
+                } else if (NR >= 2) {
+                    aa = policy_act(net1, p.n_actions, (float)price, true, (float)u, lane, (float*)nullptr);
+                } else {
+                    aa = 0;
+                }
+                aa = rfl(aa);
+                act[i] = aa;
+                scaled[i] = lane_f64(sc_tab[i], aa);
+            }
+            double a_eff = a.env.a;
+            if (noisy) {
+                const uint32_t nx = lane_u32(xn.x, tl), ny = lane_u32(xn.y, tl);
+                if (u01_32(nx) < a.env.noise_prob)
+                    a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(ny)));
+            }
+            const double next_price = env_step<THRL_MAXA>(a.env, N, scaled, a_eff, rew);
+            double val = 0.0;
+#pragma unroll
+            for (int i = 0; i < THRL_MAXA; i++) {
+                if (i >= N) continue;
+                if (a.buf_len[i] > 0) {
+                    if (lane == 0) {
+                        const size_t m = (size_t)(cnt[i] % a.buf_len[i]) * G + g;
+                        a.buf_price[i][m] = price; a.buf_action[i][m] = act[i];
+                        a.buf_reward[i][m] = rew[i]; a.buf_nprice[i][m] = next_price;
+                    }
+                    cnt[i] += 1;
+                    if (cnt[i] >= 2 * a.buf_len[i]) cnt[i] -= a.buf_len[i];
+                }
+                val = lane == i ? rew[i] : val;
+                val = lane == 32 + i ? scaled[i] : val;
+            }
+            acc = __dadd_rn(acc, __ddiv_rn(val, Td));                   // trainer.py:65-66
+            price = next_price;
+        }
+        // ---- [A.train_net() for A in agents]: the QTable agents (agents.py:59-78)
+#pragma unroll
+        for (int i = 0; i < THRL_MAXA; i++) {
+            if (i >= N) continue;
+            if (a.kind[i] != 0) continue;
+            const AgentParams& p = a.ag[i];
+            const int cap = a.buf_len[i];
+            const int len = cnt[i] < cap ? cnt[i] : cap;
+            if (cap > 0 && len >= a.min_memory[i]) {
+                T* const tab = lds + a.lds_off[i];
+                const int start = cnt[i] <= cap ? 0 : cnt[i] % cap;
+                const int A = p.n_actions;
+                __threadfence_block();             // lane 0's appends -> visible to the other lanes
+                for (int base = 0; base < len; base += 64) {            // old_value snapshot (agents.py:67)
+                    const int j = base + lane;
+                    if (j < len) {
+                        const size_t m = (size_t)((start + j) % cap) * G + g;
+                        a.buf_ov[i][m] = (double)tab[encode64(a.buf_price[i][m], p) * A + a.buf_action[i][m]];
+                    }
+                }
+                for (int base = 0; base < len; base += 64) {
+                    const int j = base + lane;
+                    int st = 0, ns = 0, ac = 0; double re = 0.0; T ov = (T)0;
+                    if (j < len) {
+                        const size_t m = (size_t)((start + j) % cap) * G + g;
+                        st = encode64(a.buf_price[i][m], p); ns = encode64(a.buf_nprice[i][m], p);
+                        ac = a.buf_action[i][m]; re = a.buf_reward[i][m]; ov = (T)a.buf_ov[i][m];
+                    }
+                    const int n = min(64, len - base);
+                    for (int k = 0; k < n; k++) {                        // serial: later entries see earlier writes
+                        const int st_k = __builtin_amdgcn_readlane(st, k), ns_k = __builtin_amdgcn_readlane(ns, k);
+                        const int ac_k = __builtin_amdgcn_readlane(ac, k);
+                        const double re_k = lane_f64(re, k);
+                        const T ov_k = lane_val(ov, k);
+                        const T nm = wave_allmax(lane < A ? tab[ns_k * A + lane] : neg_inf<T>());
+                        const T nv = td_value(ov_k, re_k, nm, p);
+                        if (lane == 0) {
+                            tab[st_k * A + ac_k] = nv;
+                            if (cg) atomicAdd(&cg[p.table_off + st_k * A + ac_k], 1);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                cnt[i] = 0;
+            }
+            eps[i] = __dadd_rn(p.eps_end, __dmul_rn(__dsub_rn(eps[i], p.eps_end), p.eps_step));
+        }
+        if (lane < N) a.game_reward_log[((size_t)e * N + lane) * G + g] = acc;
+        if (lane >= 32 && lane < 32 + N) a.game_action_log[((size_t)e * N + (lane - 32)) * G + g] = acc;
+    }
+    // ---- epilogue: tables back to HBM
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < THRL_MAXA; i++) {
+        if (i >= N) continue;
+        if (a.kind[i] != 0) continue;
+        const AgentParams& p = a.ag[i];
+        const int n = p.rows * p.n_actions;
+        for (int e = lane; e < n; e += 64) qg[p.table_off + e] = lds[a.lds_off[i] + e];
+    }
+    if (lane == 0) a.state[g] = price;
+}
+
+template <typename T, int NR, int APAD>
+int launch_one(const MixedArgs& a, hipStream_t s) {
+    auto kern = k_mixed_wave<T, NR, APAD>;
+    if (a.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           a.lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.G), dim3(64), (size_t)a.lds_bytes, s, a);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_t(const MixedArgs& a, hipStream_t s) {
+    int amax = 0;
+    for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
+    if (a.n_r == 0) return launch_one<T, 0, 8>(a, s);
+    if (a.n_r == 1) {
+        if (amax <= 8) return launch_one<T, 1, 8>(a, s);
+        if (amax <= 24) return launch_one<T, 1, 24>(a, s);
+        return launch_one<T, 1, 32>(a, s);
+    }
+    if (amax <= 8) return launch_one<T, 2, 8>(a, s);
+    if (amax <= 24) return launch_one<T, 2, 24>(a, s);
+    return launch_one<T, 2, 32>(a, s);
+}
+
+}  // namespace
+
+int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
+    const int esz = q_dtype == 1 ? 8 : 4;
+    a.n_r = 0; a.ragent[0] = a.ragent[1] = -1;
+    int off = 0;
+    for (int i = 0; i < a.N; i++) {
+        a.lds_off[i] = 0;
+        if (a.kind[i] == 1) {
+            if (a.n_r == 2) { *why = "more than two Reinforce agents"; return -1; }
+            if (a.ag[i].n_actions > kMaxA) { *why = "Reinforce agent with more than 32 actions"; return -1; }
+            a.ragent[a.n_r++] = i;
+        } else {
+            if (a.ag[i].n_actions > 64) { *why = "QTable agent with more than 64 actions"; return -1; }
+            a.lds_off[i] = off;
+            off += (a.ag[i].rows * a.ag[i].n_actions + 3) & ~3;
+        }
+    }
+    a.lds_bytes = off * esz;
+    if (a.lds_bytes > 64 * 1024) { *why = "QTable tables of one game exceed 64 KiB of LDS"; return -1; }
+    return 0;
+}
+
+int launch_mixed(const MixedArgs& a, int q_dtype, hipStream_t s) {
+    return q_dtype == 1 ? launch_t<double>(a, s) : launch_t<float>(a, s);
+}
+
+}  // namespace thrl

@@ -3,12 +3,11 @@
 // config #4: per-game independent weights make every product a tiny GEMV).
 #include <math.h>
 
-#include "thrl_device.h"
+#include "thrl_policy.h"
+#include "thrl_kernels.h"
 
 namespace thrl {
 
-constexpr int kH = THRL_NN_HIDDEN;
-constexpr int kMaxA = 32;
 constexpr uint32_t kStreamNnInit = 0x90u;
 
 __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads
@@ -37,45 +36,21 @@ __global__ void __launch_bounds__(256) k_nn_init(int G, int A, float* params, ui
     params[idx] = (2.0f * u - 1.0f) * bound;
 }
 
-// pi() + categorical sample / argmax for one game per block
+// pi() + categorical sample / argmax: one game per wavefront (thrl_policy.h), 4 games per block
+template <int APAD>
 __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __restrict__ params,
                                                  const double* __restrict__ price, const double* __restrict__ u,
                                                  int32_t* __restrict__ action_out, float* __restrict__ prob_out) {
-    __shared__ float h[kH];
-    __shared__ float z[kMaxA];
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
     const int P = 2 * kH + A * kH + A;
-    const float* w = params + (int64_t)g * P;
-    const float x = (float)price[g];
-    h[tid] = fmaxf(__fmaf_rn(w[tid], x, w[kH + tid]), 0.0f);
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int k = wave; k < A; k += 4) {
-        const float* row = w + 2 * kH + k * kH;
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kH / 64; j++) s = __fmaf_rn(row[lane + 64 * j], h[lane + 64 * j], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (lane == 0) z[k] = s + w[2 * kH + A * kH + k];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float m = z[0];
-        for (int k = 1; k < A; k++) m = fmaxf(m, z[k]);
-        float sum = 0.0f;
-        for (int k = 0; k < A; k++) { z[k] = expf(z[k] - m); sum += z[k]; }
-        int best = 0; float bv = -1.0f, c = 0.0f; int pick = A - 1; bool picked = false;
-        const float uu = u ? (float)u[g] : 0.0f;
-        for (int k = 0; k < A; k++) {
-            const float p = z[k] / sum;
-            if (prob_out) prob_out[(int64_t)g * A + k] = p;
-            if (p > bv) { bv = p; best = k; }
-            c += p;
-            if (!picked && uu < c) { pick = k; picked = true; }
-        }
-        action_out[g] = u ? pick : best;
-    }
+    PolicyRegs<APAD> r;
+    policy_load(r, params + (int64_t)g * P, A, lane);
+    float prob;
+    const int a = policy_act(r, A, (float)price[g], u != nullptr, u ? (float)u[g] : 0.0f, lane, &prob);
+    if (lane == 0) action_out[g] = a;
+    if (prob_out && !(lane & 1) && (lane >> 1) < A) prob_out[(int64_t)g * A + (lane >> 1)] = prob;
 }
 
 // train_net for one game per block (agents.py:171-193).
@@ -245,7 +220,10 @@ int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int
 }
 int launch_nn_act(int G, int A, const float* params, const double* price, const double* u, int32_t* act,
                   float* prob, hipStream_t s) {
-    hipLaunchKernelGGL(k_nn_act, dim3(G), dim3(256), 0, s, G, A, params, price, u, act, prob);
+    const dim3 grid((unsigned)((G + 3) / 4)), block(256);
+    if (A <= 8) hipLaunchKernelGGL(k_nn_act<8>, grid, block, 0, s, G, A, params, price, u, act, prob);
+    else if (A <= 24) hipLaunchKernelGGL(k_nn_act<24>, grid, block, 0, s, G, A, params, price, u, act, prob);
+    else hipLaunchKernelGGL(k_nn_act<32>, grid, block, 0, s, G, A, params, price, u, act, prob);
     return (int)hipGetLastError();
 }
 size_t nn_train_lds_bytes(int A, int N) {

@@ -152,7 +152,68 @@ class MixedGameBatch:
         idx = (torch.arange(n, device=self.device) + start) % cap
         return n, {k: v.index_select(0, idx).contiguous() for k, v in b.items()}
 
-    def run(self, n_episodes):
+    def run(self, n_episodes, fused=True):
+        """n_episodes for all games.  fused=True (default): thrl_mixed_episodes, one launch per run of
+        episodes between network updates; fused=False: the per-call operator loop (same results)."""
+        if fused:
+            return self._run_fused(int(n_episodes))
+        return self._run_unfused(int(n_episodes))
+
+    def _run_fused(self, E):
+        torch = _torch()
+        if not self.initialized:
+            raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
+        N, G, T = self.N, self.G, self.T
+        with torch.cuda.device(self.device):
+            rlog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
+            alog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
+            if not hasattr(self, "_scratch"):
+                self._scratch = [torch.zeros_like(b["price"]) if self.kinds[i] == "QTable" else None
+                                 for i, b in enumerate(self.buf)]
+            done = 0
+            while done < E:
+                k = E - done
+                for i in range(N):                     # stop where a network update is due
+                    if self.kinds[i] != "QTable" and self.buf_len[i] > 0 and self.buf_len[i] >= self.min_memory[i]:
+                        have = min(self.count[i], self.buf_len[i])
+                        need = max(1, -(-(self.min_memory[i] - have) // T))
+                        k = min(k, need)
+                mx = _lib.Mixed()
+                for i in range(N):
+                    mx.kind[i] = 0 if self.kinds[i] == "QTable" else 1
+                    if self.kinds[i] != "QTable":
+                        mx.nn_params[i] = self.nn[i].params.data_ptr()
+                    b = self.buf[i]
+                    mx.buf_price[i], mx.buf_action[i] = b["price"].data_ptr(), b["action"].data_ptr()
+                    mx.buf_reward[i], mx.buf_nprice[i] = b["reward"].data_ptr(), b["nprice"].data_ptr()
+                    if self._scratch[i] is not None:
+                        mx.buf_scratch[i] = self._scratch[i].data_ptr()
+                    mx.buf_len[i], mx.min_memory[i], mx.count[i] = self.buf_len[i], self.min_memory[i], self.count[i]
+                r = _lib.Run()
+                r.seed, r.game_offset, r.first_episode, r.n_episodes = self.seed, self.game_offset, self.episode, k
+                for i in range(N):
+                    r.eps[i] = self.eps[i]
+                _lib.check(self.L.thrl_mixed_episodes(ctypes.byref(self.cfg), ctypes.byref(mx), self._p(self.q),
+                                                      self._p(self.counter), self._p(self.state), ctypes.byref(r),
+                                                      self._p(rlog[done:]), self._p(alog[done:]), self._stream()),
+                           "thrl_mixed_episodes")
+                self.eps = [r.eps[i] for i in range(N)] + self.eps[N:]
+                self.count = [mx.count[i] for i in range(N)]
+                self.episode += k
+                done += k
+                for i in range(N):                     # Reinforce.train_net (agents.py:170-194)
+                    if self.kinds[i] != "QTable":
+                        n, b = self._ordered(i)
+                        if n >= self.min_memory[i] and n > 0:
+                            self.nn[i].train(b["price"], b["action"], b["reward"])
+                            self.count[i] = 0
+            torch.cuda.synchronize(self.device)
+            out = dict(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy(), kernel="mixed-fused")
+        out["reward_log"] = out["game_reward_log"].mean(axis=2)
+        out["action_log"] = out["game_action_log"].mean(axis=2)
+        return out
+
+    def _run_unfused(self, n_episodes):
         torch = _torch()
         if not self.initialized:
             raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
