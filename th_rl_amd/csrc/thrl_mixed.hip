@@ -29,32 +29,36 @@ template <typename T> __device__ __forceinline__ T neg_inf();
 template <> __device__ __forceinline__ float neg_inf<float>() { return -INFINITY; }
 template <> __device__ __forceinline__ double neg_inf<double>() { return -(double)INFINITY; }
 
-template <typename T, int NR, int APAD>
+// Per-agent state lives in LANES (lane i = agent i: epsilon, append count, this step's action /
+// scaled action / reward) and is picked with v_readlane, so the large bodies -- the policy, the
+// TD update -- exist once in the code, not once per agent slot.
+// Draw layout: one Philox batch covers 16 steps x 4 agent pairs, lane = pair * 16 + (step & 15).
+template <typename T, int NR, int APAD, int NA>
 __global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
-    T* const lds = reinterpret_cast<T*>(smem_mx);
+    double* const sc_tab = reinterpret_cast<double*>(smem_mx);           // [N][64] scaled action of (agent, action)
+    T* const lds = reinterpret_cast<T*>(smem_mx + (size_t)a.N * 64 * sizeof(double));
     const int g = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, G = a.G, Tn = a.T;
     const uint64_t gid = a.game_offset + (uint64_t)g;
     T* __restrict__ qg = reinterpret_cast<T*>(a.q) + (int64_t)g * a.stride;
     int32_t* __restrict__ cg = a.counter ? a.counter + (int64_t)g * a.stride : nullptr;
 
-    // ---- launch prologue: tables -> LDS, networks -> registers, per-lane scale tables
+    // ---- launch prologue: tables -> LDS, networks -> registers, scale tables, per-lane agent state
     PolicyRegs<APAD> net0, net1;
-    double sc_tab[THRL_MAXA];
-#pragma unroll
-    for (int i = 0; i < THRL_MAXA; i++) {
-        sc_tab[i] = 0.0;
-        if (i >= N) continue;
+    double eps_l = 0.0;
+    int cnt_l = 0, cap_l = 0;
+    for (int i = 0; i < N; i++) {
         const AgentParams& p = a.ag[i];
         if (a.kind[i] == 0) {
             const int n = p.rows * p.n_actions;
             for (int e = lane; e < n; e += 64) lds[a.lds_off[i] + e] = qg[p.table_off + e];
-            sc_tab[i] = scale_action(lane, p);
+            sc_tab[i * 64 + lane] = scale_action(lane, p);
         } else {
             // Reinforce.scale (agents.py:153-157): action / actions * (hi - lo) + lo
-            sc_tab[i] = __dadd_rn(__dmul_rn(__ddiv_rn((double)lane, (double)p.n_actions), p.act_span), p.act_lo);
+            sc_tab[i * 64 + lane] = __dadd_rn(__dmul_rn(__ddiv_rn((double)lane, (double)p.n_actions), p.act_span), p.act_lo);
         }
+        if (lane == i) { eps_l = a.eps0[i]; cnt_l = a.count0[i]; cap_l = a.buf_len[i]; }
     }
     if (NR >= 1) {
         const int A = a.ag[a.ragent[0]].n_actions;
@@ -68,101 +72,107 @@ __global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
     __builtin_amdgcn_wave_barrier();
 
     double price = a.state[g];
-    double eps[THRL_MAXA];
-    int cnt[THRL_MAXA];
-#pragma unroll
-    for (int i = 0; i < THRL_MAXA; i++) { eps[i] = a.eps0[i]; cnt[i] = a.count0[i]; }
     const bool noisy = a.env.noise_prob > 0.0;
     const double Td = (double)Tn;
+    const int my_agent = lane & 31;
 
     for (int e = 0; e < a.n_episodes; e++) {
         const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
         double acc = 0.0;                          // lane i: reward log of agent i ; lane 32+i: action log
-        u32x4 xs[THRL_MAXA / 2];
-        u32x4 xn = {0, 0, 0, 0};
+        u32x4 xs = {0, 0, 0, 0}, xn = {0, 0, 0, 0};
         for (int t = 0; t < Tn; t++) {
-            const int tl = t & 63;
-            if (tl == 0) {                         // draws for steps t .. t+63, one step per lane
-#pragma unroll
-                for (int pr = 0; pr < THRL_MAXA / 2; pr++)
-                    if (2 * pr < N) xs[pr] = draw(a.seed, gid, eg, (uint32_t)(t + lane), (uint32_t)pr);
-                if (noisy) xn = draw(a.seed, gid, eg, (uint32_t)(t + lane), kStreamNoise);
+            const int tl = t & 15;
+            if (tl == 0) {                         // draws for steps t .. t+15 of every agent pair
+                xs = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), (uint32_t)(lane >> 4));
+                if (noisy) xn = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), kStreamNoise);
             }
-            double scaled[THRL_MAXA], rew[THRL_MAXA];
-            int act[THRL_MAXA];
+            int act_l = 0;                         // lane i: action of agent i
+            double scaled_l = 0.0;                 // lanes i and 32+i: scaled action of agent i
+            // ---- QTable.sample_action (agents.py:80-89)
 #pragma unroll
-            for (int i = 0; i < THRL_MAXA; i++) {
-                scaled[i] = 0.0; act[i] = 0;
-                if (i >= N) continue;
+            for (int i = 0; i < NA; i++) {
+                if (i >= N || a.kind[i] != 0) continue;
                 const AgentParams& p = a.ag[i];
-                const u32x4& x = xs[i >> 1];
-                const uint32_t xu = lane_u32((i & 1) ? x.z : x.x, tl), xc = lane_u32((i & 1) ? x.w : x.y, tl);
-                const double u = u01_32(xu);
+                const int dl = (i >> 1) * 16 + tl;
+                const uint32_t xu = lane_u32((i & 1) ? xs.z : xs.x, dl), xc = lane_u32((i & 1) ? xs.w : xs.y, dl);
                 int aa;
-                if (a.kind[i] == 0) {                                   // QTable.sample_action (agents.py:80-89)
-                    if (u < eps[i]) {
-                        aa = (int)__umulhi(xc, (uint32_t)p.n_actions);
-                    } else {
-                        const int row = encode32(price, p);
-                        const T v = lane < p.n_actions ? lds[a.lds_off[i] + row * p.n_actions + lane] : neg_inf<T>();
-                        const T m = wave_allmax(v);
-                        aa = (int)__builtin_ctzll(__ballot(v == m && lane < p.n_actions));   // first max wins
-                    }
-                } else if (NR >= 1 && i == a.ragent[0]) {               // Reinforce.sample_action (agents.py:159-163)
-                    aa = policy_act(net0, p.n_actions, (float)price, true, (float)u, lane, (float*)nullptr);
-                } else if (NR >= 2) {
-                    aa = policy_act(net1, p.n_actions, (float)price, true, (float)u, lane, (float*)nullptr);
+                if (u01_32(xu) < lane_f64(eps_l, i)) {
+                    aa = (int)__umulhi(xc, (uint32_t)p.n_actions);
                 } else {
-                    aa = 0;
+                    const int row = encode32(price, p);
+                    const T v = lane < p.n_actions ? lds[a.lds_off[i] + row * p.n_actions + lane] : neg_inf<T>();
+                    const T m = wave_allmax(v);
+                    aa = (int)__builtin_ctzll(__ballot(v == m && lane < p.n_actions));       // first max wins
                 }
                 aa = rfl(aa);
-                act[i] = aa;
-                scaled[i] = lane_f64(sc_tab[i], aa);
+                const double sc = sc_tab[i * 64 + aa];
+                if (my_agent == i) { act_l = aa; scaled_l = sc; }
             }
+            // ---- Reinforce.sample_action (agents.py:159-163)
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int i = a.ragent[r];
+                const int dl = (i >> 1) * 16 + tl;
+                const uint32_t xu = lane_u32((i & 1) ? xs.z : xs.x, dl);
+                const int A = a.ag[i].n_actions;
+                int aa = policy_act(r == 0 ? net0 : net1, A, (float)price, true, (float)u01_32(xu), lane, (float*)nullptr);
+                aa = rfl(aa);
+                const double sc = sc_tab[i * 64 + aa];
+                if (my_agent == i) { act_l = aa; scaled_l = sc; }
+            }
+            // ---- NoisyPriceState.step (environments.py:25-39)
             double a_eff = a.env.a;
             if (noisy) {
                 const uint32_t nx = lane_u32(xn.x, tl), ny = lane_u32(xn.y, tl);
                 if (u01_32(nx) < a.env.noise_prob)
                     a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(ny)));
             }
-            const double next_price = env_step<THRL_MAXA>(a.env, N, scaled, a_eff, rew);
-            double val = 0.0;
+            const double A_l = __dmul_rn(a.env.ratio, scaled_l);
+            double Q = 0.0;
 #pragma unroll
-            for (int i = 0; i < THRL_MAXA; i++) {
-                if (i >= N) continue;
-                if (a.buf_len[i] > 0) {
-                    if (lane == 0) {
-                        const size_t m = (size_t)(cnt[i] % a.buf_len[i]) * G + g;
-                        a.buf_price[i][m] = price; a.buf_action[i][m] = act[i];
-                        a.buf_reward[i][m] = rew[i]; a.buf_nprice[i][m] = next_price;
-                    }
-                    cnt[i] += 1;
-                    if (cnt[i] >= 2 * a.buf_len[i]) cnt[i] -= a.buf_len[i];
+            for (int i = 0; i < NA; i++)
+                if (i < N) Q = __dadd_rn(Q, lane_f64(A_l, i));
+            double next_price = __dsub_rn(a_eff, __dmul_rn(a.env.b, Q));
+            if (!(next_price > 0.0)) next_price = 0.0;
+            const double rew_l = __dmul_rn(next_price, A_l);
+            // ---- memory.append (trainer.py:62), lane i for agent i
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                if (i >= N || a.buf_len[i] <= 0) continue;
+                if (lane == i) {
+                    const size_t m = (size_t)(cnt_l % cap_l) * G + g;
+                    a.buf_price[i][m] = price; a.buf_action[i][m] = act_l;
+                    a.buf_reward[i][m] = rew_l; a.buf_nprice[i][m] = next_price;
                 }
-                val = lane == i ? rew[i] : val;
-                val = lane == 32 + i ? scaled[i] : val;
             }
+            if (cap_l > 0) {
+                cnt_l += 1;
+                if (cnt_l >= 2 * cap_l) cnt_l -= cap_l;
+            }
+            const double val = lane < N ? rew_l : ((lane >= 32 && lane < 32 + N) ? scaled_l : 0.0);
             acc = __dadd_rn(acc, __ddiv_rn(val, Td));                   // trainer.py:65-66
             price = next_price;
         }
         // ---- [A.train_net() for A in agents]: the QTable agents (agents.py:59-78)
-#pragma unroll
-        for (int i = 0; i < THRL_MAXA; i++) {
-            if (i >= N) continue;
+        for (int i = 0; i < N; i++) {
             if (a.kind[i] != 0) continue;
             const AgentParams& p = a.ag[i];
             const int cap = a.buf_len[i];
-            const int len = cnt[i] < cap ? cnt[i] : cap;
+            const int cnt = __builtin_amdgcn_readlane(cnt_l, i);
+            const int len = cnt < cap ? cnt : cap;
             if (cap > 0 && len >= a.min_memory[i]) {
                 T* const tab = lds + a.lds_off[i];
-                const int start = cnt[i] <= cap ? 0 : cnt[i] % cap;
+                const int start = cnt <= cap ? 0 : cnt % cap;
                 const int A = p.n_actions;
-                __threadfence_block();             // lane 0's appends -> visible to the other lanes
+                const double* __restrict__ bp = a.buf_price[i]; const double* __restrict__ bn = a.buf_nprice[i];
+                const double* __restrict__ br = a.buf_reward[i]; const int32_t* __restrict__ ba = a.buf_action[i];
+                double* __restrict__ bo = a.buf_ov[i];
+                __threadfence_block();             // the appends -> visible to the other lanes
                 for (int base = 0; base < len; base += 64) {            // old_value snapshot (agents.py:67)
                     const int j = base + lane;
                     if (j < len) {
                         const size_t m = (size_t)((start + j) % cap) * G + g;
-                        a.buf_ov[i][m] = (double)tab[encode64(a.buf_price[i][m], p) * A + a.buf_action[i][m]];
+                        bo[m] = (double)tab[encode64(bp[m], p) * A + ba[m]];
                     }
                 }
                 for (int base = 0; base < len; base += 64) {
@@ -170,8 +180,8 @@ __global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
                     int st = 0, ns = 0, ac = 0; double re = 0.0; T ov = (T)0;
                     if (j < len) {
                         const size_t m = (size_t)((start + j) % cap) * G + g;
-                        st = encode64(a.buf_price[i][m], p); ns = encode64(a.buf_nprice[i][m], p);
-                        ac = a.buf_action[i][m]; re = a.buf_reward[i][m]; ov = (T)a.buf_ov[i][m];
+                        st = encode64(bp[m], p); ns = encode64(bn[m], p);
+                        ac = ba[m]; re = br[m]; ov = (T)bo[m];
                     }
                     const int n = min(64, len - base);
                     for (int k = 0; k < n; k++) {                        // serial: later entries see earlier writes
@@ -188,18 +198,16 @@ __global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
-                cnt[i] = 0;
+                if (lane == i) cnt_l = 0;
             }
-            eps[i] = __dadd_rn(p.eps_end, __dmul_rn(__dsub_rn(eps[i], p.eps_end), p.eps_step));
+            if (lane == i) eps_l = __dadd_rn(p.eps_end, __dmul_rn(__dsub_rn(eps_l, p.eps_end), p.eps_step));
         }
         if (lane < N) a.game_reward_log[((size_t)e * N + lane) * G + g] = acc;
         if (lane >= 32 && lane < 32 + N) a.game_action_log[((size_t)e * N + (lane - 32)) * G + g] = acc;
     }
     // ---- epilogue: tables back to HBM
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < THRL_MAXA; i++) {
-        if (i >= N) continue;
+    for (int i = 0; i < N; i++) {
         if (a.kind[i] != 0) continue;
         const AgentParams& p = a.ag[i];
         const int n = p.rows * p.n_actions;
@@ -208,9 +216,9 @@ __global__ void __launch_bounds__(64) k_mixed_wave(const MixedArgs a) {
     if (lane == 0) a.state[g] = price;
 }
 
-template <typename T, int NR, int APAD>
+template <typename T, int NR, int APAD, int NA>
 int launch_one(const MixedArgs& a, hipStream_t s) {
-    auto kern = k_mixed_wave<T, NR, APAD>;
+    auto kern = k_mixed_wave<T, NR, APAD, NA>;
     if (a.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            a.lds_bytes);
@@ -220,19 +228,17 @@ int launch_one(const MixedArgs& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <typename T>
-int launch_t(const MixedArgs& a, hipStream_t s) {
+template <typename T, int NA>
+int launch_na(const MixedArgs& a, hipStream_t s) {
     int amax = 0;
     for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
-    if (a.n_r == 0) return launch_one<T, 0, 8>(a, s);
-    if (a.n_r == 1) {
-        if (amax <= 8) return launch_one<T, 1, 8>(a, s);
-        if (amax <= 24) return launch_one<T, 1, 24>(a, s);
-        return launch_one<T, 1, 32>(a, s);
-    }
-    if (amax <= 8) return launch_one<T, 2, 8>(a, s);
-    if (amax <= 24) return launch_one<T, 2, 24>(a, s);
-    return launch_one<T, 2, 32>(a, s);
+    if (a.n_r == 0) return launch_one<T, 0, 24, NA>(a, s);
+    if (a.n_r == 1) return amax <= 24 ? launch_one<T, 1, 24, NA>(a, s) : launch_one<T, 1, 32, NA>(a, s);
+    return amax <= 24 ? launch_one<T, 2, 24, NA>(a, s) : launch_one<T, 2, 32, NA>(a, s);
+}
+template <typename T>
+int launch_t(const MixedArgs& a, hipStream_t s) {
+    return a.N <= 2 ? launch_na<T, 2>(a, s) : launch_na<T, THRL_MAXA>(a, s);
 }
 
 }  // namespace
@@ -253,7 +259,7 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
             off += (a.ag[i].rows * a.ag[i].n_actions + 3) & ~3;
         }
     }
-    a.lds_bytes = off * esz;
+    a.lds_bytes = a.N * 64 * 8 + off * esz;            // scale tables, then the Q-tables
     if (a.lds_bytes > 64 * 1024) { *why = "QTable tables of one game exceed 64 KiB of LDS"; return -1; }
     return 0;
 }

@@ -53,36 +53,48 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
     if (prob_out && !(lane & 1) && (lane >> 1) < A) prob_out[(int64_t)g * A + (lane >> 1)] = prob;
 }
 
-// train_net for one game per block (agents.py:171-193).
-// The n transitions are processed in chunks of kChunk: pass A (thread = transition of the chunk)
-// does the forward pass and dL/dlogits into LDS, pass B (thread = hidden unit) accumulates that
-// unit's column of every gradient over the chunk.  Chunking keeps LDS at ~50 KB per block, so
-// three blocks (12 waves) share a CU instead of one.
+// train_net for one game per block (agents.py:171-193), 256 threads.
+// The n transitions are processed in chunks of kChunk = 256:
+//   pass A1  thread = (4 transitions) x (6 actions): logits.  Each fc_pi weight read from LDS
+//            feeds 4 FMAs (packed v_pk_fma_f32), so the pass is VALU-bound, not LDS-bound.
+//   pass A2  thread = transition: softmax, entropy, d loss / d logits (in place over the logits).
+//   pass B   thread = (hidden units j, j+128) x (every other transition): that unit pair's column
+//            of every gradient; one 24-float dz row read feeds 84 FMAs.  The two transition
+//            halves are added through LDS after the last chunk.
+// Rows of fc_pi^T and of dz are padded to kPad = 24 or 32 floats (zero) for aligned vector LDS reads.
 constexpr int kChunk = 256;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+__device__ __forceinline__ int train_xs_len(int N) { return (N + kChunk - 1) / kChunk * kChunk; }
+
+template <int kPad>
 __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
         float gamma, float ent_coef, float lr, float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
-    float* W2 = reinterpret_cast<float*>(smem_nn);          // [A][kH]
-    float* w1s = W2 + A * kH;                               // [kH]
+    const int NX = train_xs_len(N);
+    float* W2t = reinterpret_cast<float*>(smem_nn);         // [kH][kPad]  fc_pi.weight transposed
+    float* dz = W2t + kH * kPad;                            // [kChunk][kPad]
+    float* xs = dz + kChunk * kPad;                         // [NX]
+    float* Gs = xs + NX;                                    // [NX]
+    float* w1s = Gs + NX;                                   // [kH]
     float* b1s = w1s + kH;                                  // [kH]
     float* b2s = b1s + kH;                                  // [kMaxA]
-    float* xs = b2s + kMaxA;                                // [N]
-    float* Gs = xs + N;                                     // [N]
-    float* dz = Gs + N;                                     // [kChunk][A]
-    float* red = dz + (size_t)kChunk * A;                   // [8]
+    float* red = b2s + kMaxA;                               // [8]
     const int g = blockIdx.x, tid = threadIdx.x;
     const int P = 2 * kH + A * kH + A;
     float* w = params + (int64_t)g * P;
 
-    for (int k = tid; k < A * kH; k += 256) W2[k] = w[2 * kH + k];
+    for (int k = 0; k < A; k++) W2t[tid * kPad + k] = w[2 * kH + k * kH + tid];
+    for (int k = A; k < kPad; k++) W2t[tid * kPad + k] = 0.0f;
     w1s[tid] = w[tid]; b1s[tid] = w[kH + tid];
-    if (tid < A) b2s[tid] = w[2 * kH + A * kH + tid];
-    for (int n = tid; n < N; n += 256) {
-        xs[n] = (float)price[(size_t)n * G + g];
-        Gs[n] = (float)reward[(size_t)n * G + g];
+    if (tid < kMaxA) b2s[tid] = tid < A ? w[2 * kH + A * kH + tid] : 0.0f;
+    for (int n = tid; n < NX; n += 256) {
+        xs[n] = n < N ? (float)price[(size_t)n * G + g] : 0.0f;
+        Gs[n] = n < N ? (float)reward[(size_t)n * G + g] : 0.0f;
     }
     __syncthreads();
     // discounted return: the reference's serial recurrence, last to first (agents.py:178-181)
@@ -99,37 +111,70 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     __syncthreads();
 
     const float invN = 1.0f / (float)N;
-    float gW2[kMaxA], col[kMaxA];
+    // pass B ownership: hidden units ja = tid & 127 and jb = ja + 128, transitions of parity tid >> 7
+    const int ja = tid & 127, jb = ja + 128, half = tid >> 7;
+    f2 gWa[kPad / 2], gWb[kPad / 2], ca[kPad / 2], cb[kPad / 2];
 #pragma unroll
-    for (int k = 0; k < kMaxA; k++) { gW2[k] = 0.0f; col[k] = k < A ? W2[k * kH + tid] : 0.0f; }
-    float gw1 = 0.0f, gb1 = 0.0f, gb2 = 0.0f;
-    const float w1j = w1s[tid], b1j = b1s[tid];
+    for (int p = 0; p < kPad / 2; p++) {
+        gWa[p] = f2{0.0f, 0.0f}; gWb[p] = f2{0.0f, 0.0f};
+        ca[p] = *reinterpret_cast<const f2*>(W2t + ja * kPad + 2 * p);
+        cb[p] = *reinterpret_cast<const f2*>(W2t + jb * kPad + 2 * p);
+    }
+    float gw1a = 0.0f, gb1a = 0.0f, gw1b = 0.0f, gb1b = 0.0f, gb2 = 0.0f;
+    const float w1a = w1s[ja], b1a = b1s[ja], w1b = w1s[jb], b1b = b1s[jb];
+    // pass A1 ownership: transitions 4q..4q+3 of the chunk, actions kPad/4 * kg .. (6 or 8 of them)
+    constexpr int kGp = kPad / 8;                           // action pairs per thread
+    const int q = tid >> 2, kg = tid & 3;
 
     for (int c0 = 0; c0 < N; c0 += kChunk) {
         const int cn = min(kChunk, N - c0);
-        // pass A (thread = transition): forward, d loss / d logits
+        {   // ---- pass A1: logits (without bias) into dz
+            const f4 x4 = *reinterpret_cast<const f4*>(xs + c0 + 4 * q);
+            f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // transitions 0..3 of the quad, kGp action pairs each
+#pragma unroll
+            for (int p = 0; p < kGp; p++) { za[p] = zb[p] = zc[p] = zd[p] = f2{0.0f, 0.0f}; }
+            const float* wrow = W2t + 2 * kGp * kg;
+#pragma unroll 4
+            for (int j = 0; j < kH; j++) {
+                const float w1 = w1s[j], b1 = b1s[j];
+                const float h0 = fmaxf(__fmaf_rn(w1, x4.x, b1), 0.0f), h1 = fmaxf(__fmaf_rn(w1, x4.y, b1), 0.0f);
+                const float h2 = fmaxf(__fmaf_rn(w1, x4.z, b1), 0.0f), h3 = fmaxf(__fmaf_rn(w1, x4.w, b1), 0.0f);
+#pragma unroll
+                for (int p = 0; p < kGp; p++) {
+                    const f2 wv = *reinterpret_cast<const f2*>(wrow + j * kPad + 2 * p);
+                    za[p] = pk_fma(wv, f2{h0, h0}, za[p]); zb[p] = pk_fma(wv, f2{h1, h1}, zb[p]);
+                    zc[p] = pk_fma(wv, f2{h2, h2}, zc[p]); zd[p] = pk_fma(wv, f2{h3, h3}, zd[p]);
+                }
+            }
+            float* o = dz + (4 * q) * kPad + 2 * kGp * kg;
+#pragma unroll
+            for (int p = 0; p < kGp; p++) {
+                *reinterpret_cast<f2*>(o + 2 * p) = za[p];
+                *reinterpret_cast<f2*>(o + kPad + 2 * p) = zb[p];
+                *reinterpret_cast<f2*>(o + 2 * kPad + 2 * p) = zc[p];
+                *reinterpret_cast<f2*>(o + 3 * kPad + 2 * p) = zd[p];
+            }
+        }
+        __syncthreads();
+        // ---- pass A2 (thread = transition): softmax, entropy, d loss / d logits
         if (tid < cn) {
             const int n = c0 + tid;
-            const float x = xs[n];
-            float zz[kMaxA];
+            float zz[kPad];
 #pragma unroll
-            for (int k = 0; k < kMaxA; k++) zz[k] = k < A ? b2s[k] : -INFINITY;
-            for (int j = 0; j < kH; j++) {
-                const float hj = fmaxf(__fmaf_rn(w1s[j], x, b1s[j]), 0.0f);
-#pragma unroll
-                for (int k = 0; k < kMaxA; k++)
-                    if (k < A) zz[k] = __fmaf_rn(W2[k * kH + j], hj, zz[k]);
+            for (int k4 = 0; k4 < kPad / 4; k4++) {
+                const f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
+                zz[4 * k4] = v.x; zz[4 * k4 + 1] = v.y; zz[4 * k4 + 2] = v.z; zz[4 * k4 + 3] = v.w;
             }
-            float m = zz[0];
+            float m = -INFINITY;
 #pragma unroll
-            for (int k = 1; k < kMaxA; k++) if (k < A) m = fmaxf(m, zz[k]);
+            for (int k = 0; k < kPad; k++) if (k < A) { zz[k] += b2s[k]; m = fmaxf(m, zz[k]); }
             float sum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < kMaxA; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
+            for (int k = 0; k < kPad; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
             float Hn = 0.0f;
-            float lp[kMaxA];
+            float lp[kPad];
 #pragma unroll
-            for (int k = 0; k < kMaxA; k++)
+            for (int k = 0; k < kPad; k++)
                 if (k < A) {
                     zz[k] = zz[k] / sum;
                     lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
@@ -138,34 +183,80 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             const int a_n = action[(size_t)n * G + g];
             const float Gn = Gs[n];
 #pragma unroll
-            for (int k = 0; k < kMaxA; k++)
-                if (k < A)
-                    dz[tid * A + k] = (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN;
+            for (int k = 0; k < kPad; k++)
+                zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < kPad / 4; k4++)
+                *reinterpret_cast<f4*>(dz + tid * kPad + 4 * k4) = f4{zz[4 * k4], zz[4 * k4 + 1], zz[4 * k4 + 2], zz[4 * k4 + 3]};
         }
         __syncthreads();
-        // pass B (thread = hidden unit j): fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j]
-        for (int i = 0; i < cn; i++) {
+        // ---- pass B: fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j] for j in {ja, jb}
+        for (int i = half; i < cn; i += 2) {
             const float x = xs[c0 + i];
-            const float pre = __fmaf_rn(w1j, x, b1j);
-            const float hj = fmaxf(pre, 0.0f);
-            float dh = 0.0f;
+            const float pa = __fmaf_rn(w1a, x, b1a), pb = __fmaf_rn(w1b, x, b1b);
+            const float ha = fmaxf(pa, 0.0f), hb = fmaxf(pb, 0.0f);
+            f2 d[kPad / 2];
 #pragma unroll
-            for (int k = 0; k < kMaxA; k++)
-                if (k < A) {
-                    const float d = dz[i * A + k];
-                    gW2[k] = __fmaf_rn(d, hj, gW2[k]);
-                    dh = __fmaf_rn(col[k], d, dh);
-                }
-            if (pre > 0.0f) { gw1 = __fmaf_rn(dh, x, gw1); gb1 += dh; }
+            for (int k4 = 0; k4 < kPad / 4; k4++) {
+                const f4 v = *reinterpret_cast<const f4*>(dz + i * kPad + 4 * k4);
+                d[2 * k4] = f2{v.x, v.y}; d[2 * k4 + 1] = f2{v.z, v.w};
+            }
+            f2 da = f2{0.0f, 0.0f}, db = f2{0.0f, 0.0f};
+#pragma unroll
+            for (int p = 0; p < kPad / 2; p++) {
+                gWa[p] = pk_fma(d[p], f2{ha, ha}, gWa[p]);
+                gWb[p] = pk_fma(d[p], f2{hb, hb}, gWb[p]);
+                da = pk_fma(ca[p], d[p], da);
+                db = pk_fma(cb[p], d[p], db);
+            }
+            const float dha = da.x + da.y, dhb = db.x + db.y;
+            if (pa > 0.0f) { gw1a = __fmaf_rn(dha, x, gw1a); gb1a += dha; }
+            if (pb > 0.0f) { gw1b = __fmaf_rn(dhb, x, gw1b); gb1b += dhb; }
         }
-        if (tid < A) for (int i = 0; i < cn; i++) gb2 += dz[i * A + tid];
+        {   // fc_pi.bias: thread (k = tid & 31, part = tid >> 5) sums every 8th row of column k
+            const int k = tid & 31;
+            if (k < A) for (int i = tid >> 5; i < cn; i += 8) gb2 += dz[i * kPad + k];
+        }
         __syncthreads();
     }
 
-    // clip_grad_norm_(1.0) (agents.py:192)
-    float sq = gw1 * gw1 + gb1 * gb1 + (tid < A ? gb2 * gb2 : 0.0f);
+    // ---- add the two transition halves (and the 8 parts of gb2) through LDS
+    float* comb = reinterpret_cast<float*>(smem_nn);        // [128][kPad * 2 + 4], over W2t / dz (no longer needed)
+    constexpr int kRow = kPad * 2 + 4;
+    if (half == 1) {
+        float* o = comb + ja * kRow;
 #pragma unroll
-    for (int k = 0; k < kMaxA; k++) if (k < A) sq += gW2[k] * gW2[k];
+        for (int p = 0; p < kPad / 2; p++) {
+            *reinterpret_cast<f2*>(o + 2 * p) = gWa[p];
+            *reinterpret_cast<f2*>(o + kPad + 2 * p) = gWb[p];
+        }
+        o[2 * kPad] = gw1a; o[2 * kPad + 1] = gb1a; o[2 * kPad + 2] = gw1b; o[2 * kPad + 3] = gb1b;
+    }
+    float* gb2s = comb + 128 * kRow;                        // [8][32]
+    gb2s[tid] = gb2;
+    __syncthreads();
+    if (half == 0) {
+        const float* o = comb + ja * kRow;
+#pragma unroll
+        for (int p = 0; p < kPad / 2; p++) {
+            gWa[p] += *reinterpret_cast<const f2*>(o + 2 * p);
+            gWb[p] += *reinterpret_cast<const f2*>(o + kPad + 2 * p);
+        }
+        gw1a += o[2 * kPad]; gb1a += o[2 * kPad + 1]; gw1b += o[2 * kPad + 2]; gb1b += o[2 * kPad + 3];
+    }
+    if (tid < A) {
+        gb2 = 0.0f;
+        for (int part = 0; part < 8; part++) gb2 += gb2s[part * 32 + tid];
+    }
+
+    // clip_grad_norm_(1.0) (agents.py:192)
+    float sq = 0.0f;
+    if (half == 0) {
+        sq = gw1a * gw1a + gb1a * gb1a + gw1b * gw1b + gb1b * gb1b;
+#pragma unroll
+        for (int p = 0; p < kPad / 2; p++) sq += gWa[p].x * gWa[p].x + gWa[p].y * gWa[p].y + gWb[p].x * gWb[p].x + gWb[p].y * gWb[p].y;
+    }
+    if (tid < A) sq += gb2 * gb2;
     const float norm = sqrtf(block_sum(sq, red));
     const float coef = fminf(1.0f, 1.0f / (norm + 1e-6f));
 
@@ -183,10 +274,15 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         mg[idx] = m; vg[idx] = v;
         w[idx] = w[idx] - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
     };
-    upd(tid, gw1);
-    upd(kH + tid, gb1);
+    if (half == 0) {
+        upd(ja, gw1a); upd(jb, gw1b);
+        upd(kH + ja, gb1a); upd(kH + jb, gb1b);
 #pragma unroll
-    for (int k = 0; k < kMaxA; k++) if (k < A) upd(2 * kH + k * kH + tid, gW2[k]);
+        for (int p = 0; p < kPad / 2; p++) {
+            if (2 * p < A) { upd(2 * kH + (2 * p) * kH + ja, gWa[p].x); upd(2 * kH + (2 * p) * kH + jb, gWb[p].x); }
+            if (2 * p + 1 < A) { upd(2 * kH + (2 * p + 1) * kH + ja, gWa[p].y); upd(2 * kH + (2 * p + 1) * kH + jb, gWb[p].y); }
+        }
+    }
     if (tid < A) upd(2 * kH + A * kH + tid, gb2);
 }
 
@@ -227,17 +323,19 @@ int launch_nn_act(int G, int A, const float* params, const double* price, const 
     return (int)hipGetLastError();
 }
 size_t nn_train_lds_bytes(int A, int N) {
-    return sizeof(float) * ((size_t)A * kH + 2 * kH + kMaxA + 2 * (size_t)N + (size_t)kChunk * A + 8);
+    const size_t pad = A <= 24 ? 24 : 32;
+    const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
+    return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8);
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, float gamma, float ent, float lr, float* grad,
                     hipStream_t s) {
     const size_t lds = nn_train_lds_bytes(A, N);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_nn_reinforce_train),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = A <= 24 ? k_nn_reinforce_train<24> : k_nn_reinforce_train<32>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_nn_reinforce_train, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price,
-                       action, reward, gamma, ent, lr, grad);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price, action, reward, gamma,
+                       ent, lr, grad);
     return (int)hipGetLastError();
 }
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
