@@ -29,7 +29,8 @@ def main():
     src = os.path.join(ROOT, "gpurun_out")
     dst = os.path.join(ROOT, "profiles")
     tag = args.tag
-    stats = glob.glob(os.path.join(src, tag + "_stats", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, tag + "_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime,
+                   reverse=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
     counters = collections.OrderedDict()
