@@ -222,15 +222,35 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
                             const double* reward, double gamma, double entropy_coef, double lr,
                             float* grad_out, void* stream);
 /*
+ * `ActorCritic` (agents.py:222-330): Reinforce's network plus a value head fc_v (256 -> 1, bias
+ * initialised to 1000, :243-244) on the shared hidden layer.  Parameter vector per game,
+ * thrl_ac_param_count(A) = thrl_nn_param_count(A) + 257 floats:
+ *   [Reinforce layout | fc_v.weight (256) | fc_v.bias (1)]
+ * thrl_ac_act = pi + sample_action / get_action (:262-272, identical to Reinforce's).
+ * thrl_ac_train = train_net (:274-305) AS THE REFERENCE EXECUTES IT: `rewards` is [N] while v and
+ * v_prime are [N,1], so advantage = (rewards + gamma*v_prime) - v broadcasts to [N,N]
+ * (advantage[i,j] = r_j + gamma*v'_i - v_i); loss = mean_ij(advantage^2 - log p_j(a_j)*advantage)
+ * + entropy_coef * (-mean H); v_prime is not detached.  next_price [n][G] = the replayed new_state.
+ */
+size_t thrl_ac_param_count(int n_actions);
+int thrl_ac_init(int n_games, int n_actions, float* params, uint64_t seed, uint64_t game_offset,
+                 int agent, void* stream);
+int thrl_ac_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
+                int32_t* action_out, float* prob_out, void* stream);
+int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
+                  int32_t step, int32_t n, const double* price, const int32_t* action,
+                  const double* reward, const double* next_price, double gamma, double entropy_coef,
+                  double lr, float* grad_out, void* stream);
+/*
  * Fused episodes for games whose agents are any mix of QTable and Reinforce (the pairing of the
  * reference's example configs): trainer.train_one's loop (trainer.py:46-70) with QTable.train_net
- * inside the kernel.  Reinforce transitions go to that agent's replay buffer; the CALLER runs
- * thrl_nn_reinforce_train when len(memory) >= min_memory and must size n_episodes so that no
+ * inside the kernel.  Reinforce / ActorCritic transitions go to that agent's replay buffer; the
+ * CALLER runs thrl_nn_reinforce_train / thrl_ac_train when len(memory) >= min_memory and must size n_episodes so that no
  * network update falls inside one call.  Replay buffers are rings [buf_len][G] per agent.
  */
 typedef struct {
-    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce                        */
-    const float* nn_params[THRL_MAXA];   /* device [G][P] for Reinforce agents               */
+    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic       */
+    const float* nn_params[THRL_MAXA];   /* device [G][P] for the neural agents              */
     double*  buf_price[THRL_MAXA];       /* device [buf_len][G] state  (trainer.py:62)       */
     int32_t* buf_action[THRL_MAXA];
     double*  buf_reward[THRL_MAXA];

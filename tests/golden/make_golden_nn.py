@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Golden fixture G7 for the neural policy path: runs the REFERENCE's Reinforce agent
-(th_rl/agents.py:119-220) here, records data only.  Usage: python tests/golden/make_golden_nn.py
+"""Golden fixtures G7 / G8 for the neural policy path: runs the REFERENCE's Reinforce
+(th_rl/agents.py:119-220) and ActorCritic (:222-330) agents here, records data only.
+Usage: python tests/golden/make_golden_nn.py
 
 Recorded: seeded initial parameters (torch default Linear init), action probabilities on
 probe states (pi(), agents.py:147-151), two consecutive train_net() calls (agents.py:170-194)
@@ -29,12 +30,26 @@ def flat(d):
 
 
 def main():
+    global PARAMS
     torch.set_num_threads(1)
+    for cls, fname, cases in (
+            ("Reinforce", "g7_reinforce.npz",
+             (("cfg", dict(gamma=0.995, actions=21, states=1, action_range=[0.2, 0.4])),
+              ("ent", dict(gamma=0.35, actions=21, states=1, action_range=[0.2, 0.4], entropy=0.01)))),
+            ("ActorCritic", "g8_actorcritic.npz",
+             (("cfg", dict(gamma=0.98, actions=21, states=1, action_range=[0.2, 0.4])),
+              ("ent", dict(gamma=0.9, actions=15, states=1, action_range=[0.2, 0.4], entropy=0.01))))):
+        PARAMS = ["fc1.weight", "fc1.bias", "fc_pi.weight", "fc_pi.bias"] + \
+                 (["fc_v.weight", "fc_v.bias"] if cls == "ActorCritic" else [])
+        one(cls, fname, cases)
+
+
+def one(cls, fname, cases):
     out = {}
-    for tag, kw in (("cfg", dict(gamma=0.995, actions=21, states=1, action_range=[0.2, 0.4])),
-                    ("ent", dict(gamma=0.35, actions=21, states=1, action_range=[0.2, 0.4], entropy=0.01))):
+    for tag, kw in cases:
         numpy.random.seed(3); random.seed(3); torch.manual_seed(3)
-        ag = ref_agents.Reinforce(**kw)
+        ag = getattr(ref_agents, cls)(**kw)
+        nA = kw["actions"]
         sd0 = {k: v.clone() for k, v in ag.state_dict().items()}
         out[tag + "_w0"] = flat(sd0)
         probe = numpy.linspace(2.0, 6.0, 9)
@@ -45,7 +60,7 @@ def main():
         rs = numpy.random.RandomState(11)
         for call in range(2):
             price = rs.randint(20, 61, size=1001) / 10.0          # on the env's price grid
-            action = rs.randint(0, 21, size=1000)
+            action = rs.randint(0, nA, size=1000)
             reward = rs.uniform(5, 15, size=1000)
             for t in range(1000):
                 ag.memory.append(numpy.array([price[t]]), numpy.int64(action[t]), float(reward[t]), True,
@@ -69,9 +84,13 @@ def main():
             out[tag + "_probe_prob2"] = numpy.stack(
                 [ag.pi(torch.from_numpy(numpy.array([p]).astype("float32"))).numpy() for p in probe])
         out[tag + "_probe_greedy2"] = numpy.array([ag.get_action(numpy.array([p])) for p in probe], "int64")
-        out[tag + "_scale"] = numpy.array([ag.scale(k) for k in range(21)])
+        out[tag + "_scale"] = numpy.array([ag.scale(k) for k in range(nA)])
         out[tag + "_kw"] = numpy.array(repr(kw))
-    p = os.path.join(HERE, "g7_reinforce.npz")
+        if cls == "ActorCritic":
+            with torch.no_grad():
+                out[tag + "_probe_value2"] = numpy.stack(
+                    [ag.v(torch.from_numpy(numpy.array([q]).astype("float32"))).numpy() for q in probe])
+    p = os.path.join(HERE, fname)
     numpy.savez_compressed(p, **out)
     print("wrote", p, os.path.getsize(p))
 

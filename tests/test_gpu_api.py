@@ -191,9 +191,9 @@ def test_train_one_rejects_unbuilt_neural_agents(tmp_path):
     from th_rl_amd import trainer
     cfgp = tmp_path / "cfg.json"
     c = _config(2)
-    c["agents"][1] = {"name": "ActorCritic", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
+    c["agents"][1] = {"name": "CAC", "gamma": 0.995, "states": 1, "action_range": [0.2, 0.4]}
     cfgp.write_text(json.dumps(c))
-    with pytest.raises(NotImplementedError, match="ActorCritic"):
+    with pytest.raises(NotImplementedError, match="CAC"):
         trainer.train_one(str(tmp_path / "r"), str(cfgp))
 
 

@@ -280,3 +280,104 @@ def test_reinforce_protocol_methods_vs_reference_fixture():
     assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4
     a = ag.sample_action(torch.tensor([3.4], dtype=torch.float32))
     assert 0 <= a <= 20 and isinstance(ag.get_action(np.array([3.4])), int)
+
+
+# ------------------------------------------------------------------------------------------------
+# ActorCritic (reference agents.py:222-330), fixture G8 (tests/golden/g8_actorcritic.npz).
+# Tolerances as for Reinforce, gradients rtol 5e-4 (the [N,N] advantage sums 10^6 float32 terms).
+GOLDEN_AC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_actorcritic.npz")
+CASES_AC = {"cfg": dict(gamma=0.98, entropy=0.0, actions=21), "ent": dict(gamma=0.9, entropy=0.01, actions=15)}
+
+
+def _ac(G, actions, **kw):
+    from th_rl_amd.nn import ActorCriticBatch
+    return ActorCriticBatch(G, actions=actions, **kw)
+
+
+@pytest.mark.parametrize("tag", sorted(CASES_AC))
+def test_actorcritic_act_and_train_match_reference(tag):
+    import torch
+    d = np.load(GOLDEN_AC)
+    kw = CASES_AC[tag]; A = kw["actions"]
+    ab = _ac(3, A, gamma=kw["gamma"], entropy=kw["entropy"]).set_params(d[tag + "_w0"])
+    assert ab.P == NN.ac_n_params(A)
+    probe = d[tag + "_probe_price"]
+    for j, pr in enumerate(probe):
+        _, probs = ab.act(np.full(3, pr), want_probs=True)
+        np.testing.assert_allclose(probs.cpu().numpy()[1], d[tag + "_probe_prob0"][j], rtol=2e-5, atol=1e-8)
+    tile = lambda x: np.repeat(np.asarray(x)[:, None], 3, axis=1)
+    for call in range(2):
+        if call == 1:        # start the second call from the reference's own state
+            ab.set_params(d[tag + "_c0_w"])
+            ab.adam_m.copy_(torch.from_numpy(np.broadcast_to(d[tag + "_c0_m"], (3, ab.P)).copy()))
+            ab.adam_v.copy_(torch.from_numpy(np.broadcast_to(d[tag + "_c0_v"], (3, ab.P)).copy()))
+            ab.step = 1
+        pr = d["%s_c%d_price" % (tag, call)]
+        g = ab.train(tile(pr[:1000]), tile(d["%s_c%d_action" % (tag, call)]), tile(d["%s_c%d_reward" % (tag, call)]),
+                     want_grad=True, next_price=tile(pr[1:1001])).cpu().numpy()
+        for k in range(3):
+            np.testing.assert_allclose(g[k], d["%s_c%d_grad" % (tag, call)], rtol=5e-4, atol=2e-6)
+        # Adam moments start from the reference's own state, so their error is the gradient's
+        # (|dg| <= 2e-6 + 5e-4|g|) propagated: m = .9 m0 + .1 g,  v = .999 v0 + .001 g^2
+        gr = np.abs(d["%s_c%d_grad" % (tag, call)].astype(np.float64))
+        dg = 2e-6 + 5e-4 * gr
+        dm = np.abs(ab.adam_m.cpu().numpy()[1].astype(np.float64) - d["%s_c%d_m" % (tag, call)])
+        dv = np.abs(ab.adam_v.cpu().numpy()[1].astype(np.float64) - d["%s_c%d_v" % (tag, call)])
+        assert np.all(dm <= 0.1 * dg + 1e-9), float((dm - 0.1 * dg).max())
+        assert np.all(dv <= 0.001 * (2 * gr * dg + dg * dg) + 1e-14), float((dv - 0.001 * (2 * gr * dg + dg * dg)).max())
+        diff = np.abs(ab.params.cpu().numpy()[2] - d["%s_c%d_w" % (tag, call)])
+        assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4, (float((diff > 5e-6).mean()), float(diff.max()))
+    for j, pr in enumerate(probe):
+        a = ab.set_params(d[tag + "_c1_w"]).act(np.full(3, pr))
+        assert int(a.cpu()[0]) == int(d[tag + "_probe_greedy2"][j])
+
+
+def test_actorcritic_many_games_vs_oracle_and_init():
+    """Independent weights per game (device init: fc_v bias 1000), ragged n, 32-action policy."""
+    G, n, A = 24, 613, 29
+    ab = _ac(G, A, gamma=0.93, entropy=0.002, seed=8).init()
+    w0 = ab.params.cpu().numpy().copy()
+    P = NN.n_params(A)
+    assert np.all(w0[:, P + 256] == 1000.0) and np.abs(w0[:, P:P + 256]).max() <= 1.0 / 16.0 + 1e-7
+    assert not np.array_equal(w0[0, P:P + 256], w0[1, P:P + 256])
+    rs = np.random.RandomState(5)
+    price = rs.randint(20, 61, (n + 1, G)) / 10.0
+    action = rs.randint(0, A, (n, G))
+    reward = rs.uniform(5, 15, (n, G))
+    g = ab.train(price[:n], action, reward, want_grad=True, next_price=price[1:]).cpu().numpy()
+    w1 = ab.params.cpu().numpy()
+    for k in (0, 11, 23):
+        ow, om, ov, os_, og = NN.ac_train_net(w0[k], np.zeros(ab.P, np.float32), np.zeros(ab.P, np.float32), 0, A,
+                                              price[:n, k], action[:, k], reward[:, k], price[1:, k], 0.93, 0.002)
+        np.testing.assert_allclose(g[k], og, rtol=5e-4, atol=2e-6)
+        diff = np.abs(w1[k] - ow)
+        assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4
+
+
+def test_actorcritic_game_fused_equals_operator_loop_and_trains(tmp_path):
+    """QTable vs ActorCritic through the fused episode kernel == the per-call operator loop
+    (bit-identical, incl. the value-head parameters after two updates); train_one writes the
+    reference's artefacts and the ActorCritic state_dict loads back."""
+    import json
+    import torch
+    from th_rl_amd import trainer
+    from th_rl_amd.mixed import MixedGameBatch
+    T = 20
+    q = dict(Q_AGENT, min_memory=T)
+    ac = {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1, "action_range": [0.2, 0.4],
+          "min_memory": 50, "entropy": 0.01}
+    config = {"agents": [q, ac], "environment": dict(ENV, max_steps=T)}
+    a = MixedGameBatch(config, n_games=4, dtype="float64", seed=2).init_tables()
+    b = MixedGameBatch(config, n_games=4, dtype="float64", seed=2).init_tables()
+    ra, rb = a.run(7, fused=True), b.run(7, fused=False)
+    assert a.nn[1].step == b.nn[1].step == 2
+    assert np.array_equal(ra["game_reward_log"], rb["game_reward_log"])
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy()) and np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.nn[1].params.cpu().numpy(), b.nn[1].params.cpu().numpy())
+    cfg = dict(config, training={"epochs": 6, "print_freq": 3, "seed": 4})
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    trainer.train_one(str(tmp_path / "run"), str(tmp_path / "c.json"))
+    sd = torch.load(tmp_path / "run" / "1", weights_only=True)
+    assert sorted(sd) == ["fc1.bias", "fc1.weight", "fc_pi.bias", "fc_pi.weight", "fc_v.bias", "fc_v.weight"]
+    assert sd["fc_v.weight"].shape == (1, 256) and abs(float(sd["fc_v.bias"]) - 1000.0) < 0.01
+    assert (tmp_path / "run" / "0.npy").exists() and (tmp_path / "run" / "log.csv").exists()

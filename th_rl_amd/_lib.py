@@ -75,7 +75,7 @@ SYMBOLS = [
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
     "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
-    "thrl_mixed_episodes",
+    "thrl_mixed_episodes", "thrl_ac_param_count", "thrl_ac_init", "thrl_ac_act", "thrl_ac_train",
 ]
 
 _lib = None
@@ -147,6 +147,15 @@ def load():
                                           dbl, dbl, dbl, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
     L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp]
+    L.thrl_ac_param_count.restype = ctypes.c_size_t
+    L.thrl_ac_param_count.argtypes = [ctypes.c_int]
+    L.thrl_ac_init.restype = ctypes.c_int
+    L.thrl_ac_init.argtypes = L.thrl_nn_init.argtypes
+    L.thrl_ac_act.restype = ctypes.c_int
+    L.thrl_ac_act.argtypes = L.thrl_nn_act.argtypes
+    L.thrl_ac_train.restype = ctypes.c_int
+    L.thrl_ac_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
+                                ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
     L.thrl_mixed_episodes.restype = ctypes.c_int
     L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
     if L.thrl_version() != 1:

@@ -134,11 +134,11 @@ class QTable:
 
 
 class _NeuralAgentBase(nn.Module):
-    """Constructor-compatible shell for the reference's torch agents: parameters and
-    save/load work (so configs and stored runs load); acting/learning is out of scope."""
+    """Common part of the reference's torch agents: parameters, memory, scale, save/load.  Reinforce and
+    ActorCritic act and learn on the device; CAC is a constructor-compatible shell (configs load)."""
 
-    _scope_note = ("neural agents are outside this round's hot path (SURVEY.md section 8f, rank 3); "
-                   "only QTable agents train on the device")
+    _scope_note = ("CAC (continuous actions) is not built yet (SURVEY.md section 8f, rank 3); "
+                   "QTable, Reinforce and ActorCritic agents train on the device")
 
     def _common(self, actions, action_range, gamma, buffer, capacity, min_memory, entropy):
         self.gamma = gamma
@@ -238,16 +238,61 @@ class Reinforce(_NeuralAgentBase):
             self.memory.empty()
 
 
-class ActorCritic(_NeuralAgentBase):
+class ActorCritic(Reinforce):
+    """The reference's actor-critic agent (agents.py:222-330): Reinforce's policy head plus the value
+    head fc_v (bias initialised to 1000, :243-244).  Acting is Reinforce's; train_net runs
+    thrl_ac_train, which reproduces the reference's [N,N]-broadcast advantage (:290)."""
+
     def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
                  capacity=50000, min_memory=1000, entropy=0, **kwargs):
-        super().__init__()
+        _NeuralAgentBase.__init__(self)
+        self.data = []
         self.fc1 = nn.Linear(states, 256)
         self.fc_pi = nn.Linear(256, actions)
         self.fc_v = nn.Linear(256, 1)
         self.fc_v.bias.data.fill_(1000.0)
         self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
         self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
+        self.states = states
+        self._rb = None
+
+    def flat_params(self):
+        return numpy.concatenate([Reinforce.flat_params(self), self.fc_v.weight.detach().numpy().ravel(),
+                                  self.fc_v.bias.detach().numpy().ravel()]).astype("float32")
+
+    def set_flat_params(self, w):
+        w = numpy.asarray(w, "float32")
+        P = 512 + self.actions * 256 + self.actions
+        Reinforce.set_flat_params(self, w[:P])
+        with torch.no_grad():
+            self.fc_v.weight.copy_(torch.from_numpy(w[P:P + 256].reshape(1, 256).copy()))
+            self.fc_v.bias.copy_(torch.from_numpy(w[P + 256:P + 257].copy()))
+
+    def _device(self):
+        if self.states != 1:
+            raise _lib.ThrlError("ActorCritic on the device needs states == 1")
+        if self._rb is None:
+            from .nn import ActorCriticBatch
+            self._rb = ActorCriticBatch(1, actions=self.actions, gamma=self.gamma, entropy=self.entropy)
+        self._rb.gamma, self._rb.entropy = float(self.gamma), float(self.entropy)
+        self._rb.set_params(self.flat_params())
+        return self._rb
+
+    def v(self, x):
+        """Value head for one state tensor (1,): host float32 arithmetic (not on the training path)."""
+        y = torch.relu(self.fc1(torch.as_tensor(x, dtype=torch.float32).reshape(-1)))
+        return self.fc_v(y).detach()
+
+    def train_net(self):
+        if len(self.memory) >= self.min_memory:
+            states, actions, rewards, done, s_prime = self.memory.replay()
+            n = len(actions)
+            rb = self._device()
+            rb.train(numpy.array(states, dtype="float64").reshape(n, 1), numpy.array(actions).reshape(n, 1),
+                     numpy.array(rewards, dtype="float64").reshape(n, 1),
+                     next_price=numpy.array(s_prime, dtype="float64").reshape(n, 1))
+            self.set_flat_params(rb.params.cpu().numpy()[0])
+            self.memory.empty()
 
 
 class CAC(_NeuralAgentBase):

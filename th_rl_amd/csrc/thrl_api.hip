@@ -521,8 +521,48 @@ int thrl_nn_init(int n_games, int n_actions, float* params, uint64_t seed, uint6
     int rc = nn_check(n_games, n_actions);
     if (rc) return rc;
     if (!params) return fail(THRL_ERR_NULL, "params is NULL");
-    const int e = launch_nn_init(n_games, n_actions, params, seed, game_offset, agent, (hipStream_t)stream);
+    const int e = launch_nn_init(n_games, n_actions, params, seed, game_offset, agent, 0, (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_init launch") : THRL_OK;
+}
+
+size_t thrl_ac_param_count(int n_actions) {
+    const size_t p = thrl_nn_param_count(n_actions);
+    return p ? p + THRL_NN_HIDDEN + 1 : 0;
+}
+
+int thrl_ac_init(int n_games, int n_actions, float* params, uint64_t seed, uint64_t game_offset, int agent,
+                 void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params) return fail(THRL_ERR_NULL, "params is NULL");
+    const int e = launch_nn_init(n_games, n_actions, params, seed, game_offset, agent, 1, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_init launch") : THRL_OK;
+}
+
+int thrl_ac_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
+                int32_t* action_out, float* prob_out, void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params || !price || !action_out) return fail(THRL_ERR_NULL, "params/price/action_out is NULL");
+    const int e = launch_nn_act(n_games, n_actions, params, (int)thrl_ac_param_count(n_actions), price, u, action_out,
+                                prob_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_act launch") : THRL_OK;
+}
+
+int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
+                  const double* price, const int32_t* action, const double* reward, const double* next_price,
+                  double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+    int rc = nn_check(n_games, n_actions);
+    if (rc) return rc;
+    if (!params || !adam_m || !adam_v || !price || !action || !reward || !next_price)
+        return fail(THRL_ERR_NULL, "a required pointer is NULL");
+    if (n < 2 || n > THRL_NN_MAX_TRANSITIONS)
+        return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions out of [2,%d]", n, THRL_NN_MAX_TRANSITIONS);
+    if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
+    if (nn_train_lds_bytes(n_actions, n, 1) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
+    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, next_price,
+                                  (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_nn_reinforce_train<AC> launch") : THRL_OK;
 }
 
 int thrl_nn_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
@@ -530,7 +570,8 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
     int rc = nn_check(n_games, n_actions);
     if (rc) return rc;
     if (!params || !price || !action_out) return fail(THRL_ERR_NULL, "params/price/action_out is NULL");
-    const int e = launch_nn_act(n_games, n_actions, params, price, u, action_out, prob_out, (hipStream_t)stream);
+    const int e = launch_nn_act(n_games, n_actions, params, (int)thrl_nn_param_count(n_actions), price, u, action_out,
+                                prob_out, (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_act launch") : THRL_OK;
 }
 
@@ -543,8 +584,8 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
     if (n < 2 || n > THRL_NN_MAX_TRANSITIONS)
         return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions out of [2,%d]", n, THRL_NN_MAX_TRANSITIONS);
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
-    if (nn_train_lds_bytes(n_actions, n) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
-    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward,
+    if (nn_train_lds_bytes(n_actions, n, 0) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
+    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, nullptr,
                                   (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
 }
@@ -566,9 +607,11 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
     a.game_reward_log = game_reward_log; a.game_action_log = game_action_log;
     a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
     for (int i = 0; i < c->n_agents; i++) {
-        if (mx->kind[i] != 0 && mx->kind[i] != 1) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
-        if (mx->kind[i] == 1 && (!mx->nn_params[i] || c->n_actions[i] > 32))
-            return fail(THRL_ERR_NULL, "agent %d: Reinforce needs nn_params and actions <= 32", i);
+        if (mx->kind[i] < 0 || mx->kind[i] > 2) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
+        if (mx->kind[i] != 0 && (!mx->nn_params[i] || c->n_actions[i] > 32))
+            return fail(THRL_ERR_NULL, "agent %d: a neural agent needs nn_params and actions <= 32", i);
+        a.nn_stride[i] = mx->kind[i] == 2 ? (int32_t)thrl_ac_param_count(c->n_actions[i])
+                                          : (int32_t)thrl_nn_param_count(c->n_actions[i]);
         if (mx->buf_len[i] > 0 && (!mx->buf_price[i] || !mx->buf_action[i] || !mx->buf_reward[i] || !mx->buf_nprice[i]))
             return fail(THRL_ERR_NULL, "agent %d: replay buffer pointers are NULL", i);
         if (mx->kind[i] == 0 && mx->buf_len[i] > 0 && !mx->buf_scratch[i])

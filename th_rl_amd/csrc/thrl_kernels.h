@@ -121,9 +121,10 @@ struct MixedArgs {
     int64_t stride;
     EnvParams env;
     AgentParams ag[THRL_MAXA];            // QTable parameters; for a Reinforce slot: n_actions, act_lo, act_span
-    int32_t kind[THRL_MAXA];              // 0 = QTable, 1 = Reinforce
+    int32_t kind[THRL_MAXA];              // 0 = QTable, 1 = Reinforce, 2 = ActorCritic (same policy head)
     void* q; int32_t* counter; double* state;
-    const float* nn_params[THRL_MAXA];    // [G][P] per Reinforce agent
+    const float* nn_params[THRL_MAXA];    // [G][nn_stride] per Reinforce / ActorCritic agent
+    int32_t nn_stride[THRL_MAXA];
     double* buf_price[THRL_MAXA]; int32_t* buf_action[THRL_MAXA];      // replay buffers [buf_len][G]
     double* buf_reward[THRL_MAXA]; double* buf_nprice[THRL_MAXA]; double* buf_ov[THRL_MAXA];
     int32_t buf_len[THRL_MAXA]; int32_t min_memory[THRL_MAXA]; int32_t count0[THRL_MAXA];
@@ -137,12 +138,14 @@ struct MixedArgs {
 // fills n_r / ragent / lds_off / lds_bytes; returns 0 or -1 with a reason when the config does not fit
 int plan_mixed(MixedArgs& a, int q_dtype, const char** why);
 int launch_mixed(const MixedArgs& a, int q_dtype, hipStream_t s);
-int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s);
-int launch_nn_act(int G, int A, const float* params, const double* price, const double* u, int32_t* act,
+int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, int value_head, hipStream_t s);
+int launch_nn_act(int G, int A, const float* params, int P, const double* price, const double* u, int32_t* act,
                   float* prob, hipStream_t s);
-size_t nn_train_lds_bytes(int A, int N);
+size_t nn_train_lds_bytes(int A, int N, int value_head);
+// nprice != NULL: ActorCritic update (value head, params stride P + 257); NULL: Reinforce
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
-                    const int32_t* action, const double* reward, float gamma, float ent, float lr, float* grad,
+                    const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
+                    float* grad,
                     hipStream_t s);
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
                     double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* nu, double* na, hipStream_t s);

@@ -63,11 +63,11 @@ k_mixed_wave(const MixedArgs a) {
     }
     if (NR >= 1) {
         const int A = a.ag[a.ragent[0]].n_actions;
-        policy_load(net0, a.nn_params[a.ragent[0]] + (int64_t)g * (2 * kH + A * kH + A), A, lane);
+        policy_load(net0, a.nn_params[a.ragent[0]] + (int64_t)g * a.nn_stride[a.ragent[0]], A, lane);
     }
     if (NR >= 2) {
         const int A = a.ag[a.ragent[1]].n_actions;
-        policy_load(net1, a.nn_params[a.ragent[1]] + (int64_t)g * (2 * kH + A * kH + A), A, lane);
+        policy_load(net1, a.nn_params[a.ragent[1]] + (int64_t)g * a.nn_stride[a.ragent[1]], A, lane);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -250,9 +250,9 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
     int off = 0;
     for (int i = 0; i < a.N; i++) {
         a.lds_off[i] = 0;
-        if (a.kind[i] == 1) {
-            if (a.n_r == 2) { *why = "more than two Reinforce agents"; return -1; }
-            if (a.ag[i].n_actions > kMaxA) { *why = "Reinforce agent with more than 32 actions"; return -1; }
+        if (a.kind[i] != 0) {
+            if (a.n_r == 2) { *why = "more than two neural agents"; return -1; }
+            if (a.ag[i].n_actions > kMaxA) { *why = "neural agent with more than 32 actions"; return -1; }
             a.ragent[a.n_r++] = i;
         } else {
             if (a.ag[i].n_actions > 64) { *why = "QTable agent with more than 64 actions"; return -1; }

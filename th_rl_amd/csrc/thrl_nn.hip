@@ -23,28 +23,29 @@ __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threa
 
 // torch.nn.Linear.reset_parameters: weight ~ kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +),
 // bias ~ U(-1/sqrt(fan_in), +)
+// value_head: ActorCritic's fc_v (256 -> 1) appended, bias filled with 1000 (agents.py:243-244)
 __global__ void __launch_bounds__(256) k_nn_init(int G, int A, float* params, uint64_t seed,
-                                                  uint64_t game_offset, int agent) {
-    const int P = 2 * kH + A * kH + A;
+                                                  uint64_t game_offset, int agent, int value_head) {
+    const int Pp = 2 * kH + A * kH + A;
+    const int P = Pp + (value_head ? kH + 1 : 0);
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)G * P) return;
     const int g = (int)(idx / P), j = (int)(idx - (int64_t)g * P);
     const u32x4 x = draw(seed, game_offset + (uint64_t)g, (uint32_t)agent, (uint32_t)(j >> 2), kStreamNnInit);
     const uint32_t r = (j & 3) == 0 ? x.x : ((j & 3) == 1 ? x.y : ((j & 3) == 2 ? x.z : x.w));
     const float u = (float)((double)r * 0x1p-32);                      // [0,1)
-    const float bound = j < 2 * kH ? 1.0f : 1.0f / sqrtf((float)kH);   // fan_in = 1 for fc1, 256 for fc_pi
-    params[idx] = (2.0f * u - 1.0f) * bound;
+    const float bound = j < 2 * kH ? 1.0f : 1.0f / sqrtf((float)kH);   // fan_in = 1 for fc1, 256 for fc_pi / fc_v
+    params[idx] = j == Pp + kH ? 1000.0f : (2.0f * u - 1.0f) * bound;
 }
 
 // pi() + categorical sample / argmax: one game per wavefront (thrl_policy.h), 4 games per block
 template <int APAD>
-__global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __restrict__ params,
+__global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __restrict__ params, int P,
                                                  const double* __restrict__ price, const double* __restrict__ u,
                                                  int32_t* __restrict__ action_out, float* __restrict__ prob_out) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= G) return;
-    const int P = 2 * kH + A * kH + A;
     PolicyRegs<APAD> r;
     policy_load(r, params + (int64_t)g * P, A, lane);
     float prob;
@@ -69,11 +70,15 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 
 __device__ __forceinline__ int train_xs_len(int N) { return (N + kChunk - 1) / kChunk * kChunk; }
 
-template <int kPad>
+// AC = true: ActorCritic.train_net (agents.py:280-305) as the reference executes it -- `rewards` [N]
+// against v / v_prime [N,1] broadcasts the advantage to [N,N], adv[i,j] = r_j + gamma*v'_i - v_i;
+// its row sums drive the critic (d loss/d v_i = -(2/N^2)(R + N c_i), c_i = gamma*v'_i - v_i, v' not
+// detached) and its column sums the actor (weight r_j + C/N in place of Reinforce's return).
+template <int kPad, bool AC>
 __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
-        float gamma, float ent_coef, float lr, float* __restrict__ grad_out) {
+        const double* __restrict__ nprice, float gamma, float ent_coef, float lr, float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
     const int NX = train_xs_len(N);
     float* W2t = reinterpret_cast<float*>(smem_nn);         // [kH][kPad]  fc_pi.weight transposed
@@ -84,8 +89,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     float* b1s = w1s + kH;                                  // [kH]
     float* b2s = b1s + kH;                                  // [kMaxA]
     float* red = b2s + kMaxA;                               // [8]
+    float* xps = red + 8;                                   // [NX]  next states           (AC only)
+    float* gvs = xps + (AC ? NX : 0);                       // [NX]  c_i, then d loss/d v_i (AC only)
+    float* wvs = gvs + (AC ? NX : 0);                       // [kH]  fc_v.weight            (AC only)
     const int g = blockIdx.x, tid = threadIdx.x;
-    const int P = 2 * kH + A * kH + A;
+    const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
+    const int P = Pp + (AC ? kH + 1 : 0);
     float* w = params + (int64_t)g * P;
 
     for (int k = 0; k < A; k++) W2t[tid * kPad + k] = w[2 * kH + k * kH + tid];
@@ -95,19 +104,49 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     for (int n = tid; n < NX; n += 256) {
         xs[n] = n < N ? (float)price[(size_t)n * G + g] : 0.0f;
         Gs[n] = n < N ? (float)reward[(size_t)n * G + g] : 0.0f;
+        if (AC) xps[n] = n < N ? (float)nprice[(size_t)n * G + g] : 0.0f;
     }
+    if (AC) wvs[tid] = w[Pp + tid];
     __syncthreads();
-    // discounted return: the reference's serial recurrence, last to first (agents.py:178-181)
-    if (tid == 0)
-        for (int n = N - 2; n >= 0; n--) Gs[n] = __fadd_rn(Gs[n], __fmul_rn(gamma, Gs[n + 1]));
-    __syncthreads();
-    float part = 0.0f;
-    for (int n = tid; n < N; n += 256) part += Gs[n];
-    const float mean = block_sum(part, red) / (float)N;
-    part = 0.0f;
-    for (int n = tid; n < N; n += 256) { const float d = Gs[n] - mean; part += d * d; }
-    const float sd = sqrtf(block_sum(part, red) / (float)(N - 1));      // torch.std: unbiased
-    for (int n = tid; n < N; n += 256) Gs[n] = (Gs[n] - mean) / sd;
+    float wva = 0.0f, wvb = 0.0f, gbv = 0.0f;
+    if (!AC) {
+        // discounted return: the reference's serial recurrence, last to first (agents.py:178-181)
+        if (tid == 0)
+            for (int n = N - 2; n >= 0; n--) Gs[n] = __fadd_rn(Gs[n], __fmul_rn(gamma, Gs[n + 1]));
+        __syncthreads();
+        float part = 0.0f;
+        for (int n = tid; n < N; n += 256) part += Gs[n];
+        const float mean = block_sum(part, red) / (float)N;
+        part = 0.0f;
+        for (int n = tid; n < N; n += 256) { const float d = Gs[n] - mean; part += d * d; }
+        const float sd = sqrtf(block_sum(part, red) / (float)(N - 1));      // torch.std: unbiased
+        for (int n = tid; n < N; n += 256) Gs[n] = (Gs[n] - mean) / sd;
+    } else {
+        // v(s), v(s') per transition (agents.py:287-288), c_i = gamma*v'_i - v_i
+        const float bv = w[Pp + kH];
+        float cpart = 0.0f, rpart = 0.0f;
+        for (int n = tid; n < N; n += 256) {
+            const float x = xs[n], xp = xps[n];
+            float v = bv, vp = bv;
+            for (int j = 0; j < kH; j++) {
+                const float w1 = w1s[j], b1 = b1s[j], wv = wvs[j];
+                v = __fmaf_rn(wv, fmaxf(__fmaf_rn(w1, x, b1), 0.0f), v);
+                vp = __fmaf_rn(wv, fmaxf(__fmaf_rn(w1, xp, b1), 0.0f), vp);
+            }
+            const float c = gamma * vp - v;
+            gvs[n] = c; cpart += c; rpart += Gs[n];
+        }
+        const float C = block_sum(cpart, red), R = block_sum(rpart, red);
+        const float fN = (float)N;
+        float gpart = 0.0f;
+        for (int n = tid; n < N; n += 256) {
+            Gs[n] = Gs[n] + C / fN;                                       // column sums of adv / N
+            const float gv = -(2.0f / (fN * fN)) * (R + fN * gvs[n]);      // - row sums of adv * 2/N^2
+            gvs[n] = gv; gpart += gv;
+        }
+        gbv = (1.0f - gamma) * block_sum(gpart, red);                     // sum_i (gv_i + gv'_i), gv' = -gamma*gv
+        wva = wvs[tid & 127]; wvb = wvs[(tid & 127) + 128];
+    }
     __syncthreads();
 
     const float invN = 1.0f / (float)N;
@@ -120,7 +159,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         ca[p] = *reinterpret_cast<const f2*>(W2t + ja * kPad + 2 * p);
         cb[p] = *reinterpret_cast<const f2*>(W2t + jb * kPad + 2 * p);
     }
-    float gw1a = 0.0f, gb1a = 0.0f, gw1b = 0.0f, gb1b = 0.0f, gb2 = 0.0f;
+    float gw1a = 0.0f, gb1a = 0.0f, gw1b = 0.0f, gb1b = 0.0f, gb2 = 0.0f, gwva = 0.0f, gwvb = 0.0f;
     const float w1a = w1s[ja], b1a = b1s[ja], w1b = w1s[jb], b1b = b1s[jb];
     // pass A1 ownership: transitions 4q..4q+3 of the chunk, actions kPad/4 * kg .. (6 or 8 of them)
     constexpr int kGp = kPad / 8;                           // action pairs per thread
@@ -209,7 +248,17 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                 da = pk_fma(ca[p], d[p], da);
                 db = pk_fma(cb[p], d[p], db);
             }
-            const float dha = da.x + da.y, dhb = db.x + db.y;
+            float dha = da.x + da.y, dhb = db.x + db.y;
+            if (AC) {
+                const float gv = gvs[c0 + i], gvp = -gamma * gv, xp = xps[c0 + i];
+                const float qa = __fmaf_rn(w1a, xp, b1a), qb = __fmaf_rn(w1b, xp, b1b);
+                gwva = __fmaf_rn(gv, ha, gwva); gwva = __fmaf_rn(gvp, fmaxf(qa, 0.0f), gwva);
+                gwvb = __fmaf_rn(gv, hb, gwvb); gwvb = __fmaf_rn(gvp, fmaxf(qb, 0.0f), gwvb);
+                dha = __fmaf_rn(gv, wva, dha); dhb = __fmaf_rn(gv, wvb, dhb);
+                const float ea = gvp * wva, eb = gvp * wvb;               // d loss / d h' through fc_v
+                if (qa > 0.0f) { gw1a = __fmaf_rn(ea, xp, gw1a); gb1a += ea; }
+                if (qb > 0.0f) { gw1b = __fmaf_rn(eb, xp, gw1b); gb1b += eb; }
+            }
             if (pa > 0.0f) { gw1a = __fmaf_rn(dha, x, gw1a); gb1a += dha; }
             if (pb > 0.0f) { gw1b = __fmaf_rn(dhb, x, gw1b); gb1b += dhb; }
         }
@@ -222,7 +271,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
 
     // ---- add the two transition halves (and the 8 parts of gb2) through LDS
     float* comb = reinterpret_cast<float*>(smem_nn);        // [128][kPad * 2 + 4], over W2t / dz (no longer needed)
-    constexpr int kRow = kPad * 2 + 4;
+    constexpr int kRow = kPad * 2 + 6;
     if (half == 1) {
         float* o = comb + ja * kRow;
 #pragma unroll
@@ -231,6 +280,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             *reinterpret_cast<f2*>(o + kPad + 2 * p) = gWb[p];
         }
         o[2 * kPad] = gw1a; o[2 * kPad + 1] = gb1a; o[2 * kPad + 2] = gw1b; o[2 * kPad + 3] = gb1b;
+        o[2 * kPad + 4] = gwva; o[2 * kPad + 5] = gwvb;
     }
     float* gb2s = comb + 128 * kRow;                        // [8][32]
     gb2s[tid] = gb2;
@@ -243,6 +293,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             gWb[p] += *reinterpret_cast<const f2*>(o + kPad + 2 * p);
         }
         gw1a += o[2 * kPad]; gb1a += o[2 * kPad + 1]; gw1b += o[2 * kPad + 2]; gb1b += o[2 * kPad + 3];
+        gwva += o[2 * kPad + 4]; gwvb += o[2 * kPad + 5];
     }
     if (tid < A) {
         gb2 = 0.0f;
@@ -252,11 +303,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     // clip_grad_norm_(1.0) (agents.py:192)
     float sq = 0.0f;
     if (half == 0) {
-        sq = gw1a * gw1a + gb1a * gb1a + gw1b * gw1b + gb1b * gb1b;
+        sq = gw1a * gw1a + gb1a * gb1a + gw1b * gw1b + gb1b * gb1b + gwva * gwva + gwvb * gwvb;
 #pragma unroll
         for (int p = 0; p < kPad / 2; p++) sq += gWa[p].x * gWa[p].x + gWa[p].y * gWa[p].y + gWb[p].x * gWb[p].x + gWb[p].y * gWb[p].y;
     }
     if (tid < A) sq += gb2 * gb2;
+    if (AC && tid == 255) sq += gbv * gbv;
     const float norm = sqrtf(block_sum(sq, red));
     const float coef = fminf(1.0f, 1.0f / (norm + 1e-6f));
 
@@ -284,6 +336,10 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         }
     }
     if (tid < A) upd(2 * kH + A * kH + tid, gb2);
+    if (AC) {
+        if (half == 0) { upd(Pp + ja, gwva); upd(Pp + jb, gwvb); }
+        if (tid == 255) upd(Pp + kH, gbv);
+    }
 }
 
 // Philox draws of one lockstep step (same counters as the episode kernels)
@@ -309,33 +365,36 @@ __global__ void __launch_bounds__(256) k_op_draws(int G, int N, uint64_t seed, u
     }
 }
 
-int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s) {
-    const int64_t n = (int64_t)G * (2 * kH + A * kH + A);
-    hipLaunchKernelGGL(k_nn_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, A, params, seed, off, agent);
+int launch_nn_init(int G, int A, float* params, uint64_t seed, uint64_t off, int agent, int value_head, hipStream_t s) {
+    const int64_t n = (int64_t)G * (2 * kH + A * kH + A + (value_head ? kH + 1 : 0));
+    hipLaunchKernelGGL(k_nn_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, G, A, params, seed, off, agent,
+                       value_head);
     return (int)hipGetLastError();
 }
-int launch_nn_act(int G, int A, const float* params, const double* price, const double* u, int32_t* act,
+int launch_nn_act(int G, int A, const float* params, int P, const double* price, const double* u, int32_t* act,
                   float* prob, hipStream_t s) {
     const dim3 grid((unsigned)((G + 3) / 4)), block(256);
-    if (A <= 8) hipLaunchKernelGGL(k_nn_act<8>, grid, block, 0, s, G, A, params, price, u, act, prob);
-    else if (A <= 24) hipLaunchKernelGGL(k_nn_act<24>, grid, block, 0, s, G, A, params, price, u, act, prob);
-    else hipLaunchKernelGGL(k_nn_act<32>, grid, block, 0, s, G, A, params, price, u, act, prob);
+    if (A <= 8) hipLaunchKernelGGL(k_nn_act<8>, grid, block, 0, s, G, A, params, P, price, u, act, prob);
+    else if (A <= 24) hipLaunchKernelGGL(k_nn_act<24>, grid, block, 0, s, G, A, params, P, price, u, act, prob);
+    else hipLaunchKernelGGL(k_nn_act<32>, grid, block, 0, s, G, A, params, P, price, u, act, prob);
     return (int)hipGetLastError();
 }
-size_t nn_train_lds_bytes(int A, int N) {
+size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
-    return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8);
+    return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
+                            (value_head ? 2 * nx + kH : 0));
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
-                    const int32_t* action, const double* reward, float gamma, float ent, float lr, float* grad,
-                    hipStream_t s) {
-    const size_t lds = nn_train_lds_bytes(A, N);
-    auto kern = A <= 24 ? k_nn_reinforce_train<24> : k_nn_reinforce_train<32>;
+                    const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
+                    float* grad, hipStream_t s) {
+    const size_t lds = nn_train_lds_bytes(A, N, nprice != nullptr);
+    auto kern = nprice ? (A <= 24 ? k_nn_reinforce_train<24, true> : k_nn_reinforce_train<32, true>)
+                       : (A <= 24 ? k_nn_reinforce_train<24, false> : k_nn_reinforce_train<32, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price, action, reward, gamma,
-                       ent, lr, grad);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price, action, reward, nprice,
+                       gamma, ent, lr, grad);
     return (int)hipGetLastError();
 }
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,

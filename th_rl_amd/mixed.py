@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import ThrlError
 from .batched import _require_gpu, _torch
-from .nn import ReinforceBatch
+from .nn import ActorCriticBatch, ReinforceBatch
 
 NN_DEFAULTS = dict(states=4, actions=2, action_range=[0, 1], gamma=0.98, capacity=50000, min_memory=1000,
                    entropy=0)
@@ -36,8 +36,8 @@ class MixedGameBatch:
         self.dtype = {"float32": 0, "float64": 1}[str(dtype)]
         self.kinds = [a.get("name", "QTable") for a in config["agents"]]
         for k in self.kinds:
-            if k not in ("QTable", "Reinforce"):
-                raise NotImplementedError("device path: agent %r is not supported (QTable, Reinforce)" % k)
+            if k not in ("QTable", "Reinforce", "ActorCritic"):
+                raise NotImplementedError("device path: agent %r is not supported (QTable, Reinforce, ActorCritic)" % k)
         # thrl_cfg for the operators: a Reinforce agent occupies a dummy 2-row table slot
         as_q = []
         self.nn_cfg = {}
@@ -47,7 +47,7 @@ class MixedGameBatch:
             else:
                 p = dict(NN_DEFAULTS, **a)
                 if int(p["states"]) != 1:
-                    raise ThrlError("Reinforce on the device needs states == 1 (the env state is one number)")
+                    raise ThrlError("%s on the device needs states == 1 (the env state is one number)" % self.kinds[i])
                 self.nn_cfg[i] = p
                 as_q.append(dict(name="QTable", states=1, actions=int(p["actions"]), action_range=p["action_range"],
                                  capacity=1, min_memory=1))
@@ -63,9 +63,9 @@ class MixedGameBatch:
             self.q = torch.zeros((self.G, self.stride), dtype=tdt, device=self.device)
             self.counter = torch.zeros((self.G, self.stride), dtype=torch.int32, device=self.device)
             self.state = torch.zeros((self.G,), dtype=torch.float64, device=self.device)
-        self.nn = {i: ReinforceBatch(self.G, actions=int(p["actions"]), gamma=float(p["gamma"]),
-                                     entropy=float(p["entropy"]), device=device, seed=seed, game_offset=game_offset,
-                                     agent_index=i) for i, p in self.nn_cfg.items()}
+        self.nn = {i: (ActorCriticBatch if self.kinds[i] == "ActorCritic" else ReinforceBatch)(
+            self.G, actions=int(p["actions"]), gamma=float(p["gamma"]), entropy=float(p["entropy"]), device=device,
+            seed=seed, game_offset=game_offset, agent_index=i) for i, p in self.nn_cfg.items()}
         self.cap = [int(self.cfg.capacity[i]) if self.kinds[i] == "QTable" else int(self.nn_cfg[i]["capacity"])
                     for i in range(self.N)]
         self.min_memory = [int(self.cfg.min_memory[i]) if self.kinds[i] == "QTable" else int(self.nn_cfg[i]["min_memory"])
@@ -180,7 +180,7 @@ class MixedGameBatch:
                         k = min(k, need)
                 mx = _lib.Mixed()
                 for i in range(N):
-                    mx.kind[i] = 0 if self.kinds[i] == "QTable" else 1
+                    mx.kind[i] = {"QTable": 0, "Reinforce": 1, "ActorCritic": 2}[self.kinds[i]]
                     if self.kinds[i] != "QTable":
                         mx.nn_params[i] = self.nn[i].params.data_ptr()
                     b = self.buf[i]
@@ -205,7 +205,7 @@ class MixedGameBatch:
                     if self.kinds[i] != "QTable":
                         n, b = self._ordered(i)
                         if n >= self.min_memory[i] and n > 0:
-                            self.nn[i].train(b["price"], b["action"], b["reward"])
+                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"])
                             self.count[i] = 0
             torch.cuda.synchronize(self.device)
             out = dict(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy(), kernel="mixed-fused")
@@ -272,7 +272,7 @@ class MixedGameBatch:
                                        "thrl_op_td_update")
                             torch.cuda.synchronize(self.device)
                         else:
-                            self.nn[i].train(b["price"], b["action"], b["reward"])
+                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"])
                         self.count[i] = 0
                     if self.kinds[i] == "QTable":                # epsilon decays on every call (agents.py:78)
                         self.eps[i] = self.cfg.eps_end[i] + (self.eps[i] - self.cfg.eps_end[i]) * self.cfg.eps_step[i]

@@ -11,6 +11,9 @@ from .batched import _require_gpu, _torch
 
 
 class ReinforceBatch:
+    value_head = False          # ActorCriticBatch: fc_v appended to the parameter vector
+    _fn = dict(count="thrl_nn_param_count", init="thrl_nn_init", act="thrl_nn_act")
+
     def __init__(self, n_games, actions=2, gamma=0.98, entropy=0.0, lr=2e-4, device="cuda:0", seed=0,
                  game_offset=0, agent_index=0):
         self.L = _lib.load()
@@ -19,9 +22,9 @@ class ReinforceBatch:
         self.G, self.A = int(n_games), int(actions)
         self.gamma, self.entropy, self.lr = float(gamma), float(entropy), float(lr)
         self.seed, self.game_offset, self.agent_index = int(seed), int(game_offset), int(agent_index)
-        self.P = int(self.L.thrl_nn_param_count(self.A))
+        self.P = int(getattr(self.L, self._fn["count"])(self.A))
         if self.P == 0:
-            raise ThrlError("Reinforce on the device needs 2 <= actions <= 32, got %d" % self.A)
+            raise ThrlError("%s on the device needs 2 <= actions <= 32, got %d" % (type(self).__name__, self.A))
         with torch.cuda.device(self.device):
             self.params = torch.zeros((self.G, self.P), dtype=torch.float32, device=self.device)
             self.adam_m = torch.zeros_like(self.params)
@@ -44,8 +47,9 @@ class ReinforceBatch:
     def init(self):
         torch = _torch()
         with torch.cuda.device(self.device):
-            _lib.check(self.L.thrl_nn_init(self.G, self.A, self._p(self.params), self.seed, self.game_offset,
-                                           self.agent_index, self._stream()), "thrl_nn_init")
+            _lib.check(getattr(self.L, self._fn["init"])(self.G, self.A, self._p(self.params), self.seed,
+                                                         self.game_offset, self.agent_index, self._stream()),
+                       self._fn["init"])
         self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
         return self
 
@@ -62,11 +66,12 @@ class ReinforceBatch:
             d_u = None if u is None else self._dev(u, torch.float64).reshape(self.G)
             out = torch.zeros((self.G,), dtype=torch.int32, device=self.device)
             probs = torch.zeros((self.G, self.A), dtype=torch.float32, device=self.device) if want_probs else None
-            _lib.check(self.L.thrl_nn_act(self.G, self.A, self._p(self.params), self._p(d_price), self._p(d_u),
-                                          self._p(out), self._p(probs), self._stream()), "thrl_nn_act")
+            _lib.check(getattr(self.L, self._fn["act"])(self.G, self.A, self._p(self.params), self._p(d_price),
+                                                        self._p(d_u), self._p(out), self._p(probs), self._stream()),
+                       self._fn["act"])
         return (out, probs) if want_probs else out
 
-    def train(self, price, action, reward, want_grad=False):
+    def train(self, price, action, reward, want_grad=False, next_price=None):
         """One train_net update on n transitions per game: arrays [n, G]."""
         torch = _torch()
         with torch.cuda.device(self.device):
@@ -79,6 +84,32 @@ class ReinforceBatch:
                                                       self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a),
                                                       self._p(d_r), self.gamma, self.entropy, self.lr,
                                                       self._p(grad), self._stream()), "thrl_nn_reinforce_train")
+            torch.cuda.synchronize(self.device)
+        self.step += 1
+        return grad
+
+
+class ActorCriticBatch(ReinforceBatch):
+    """The reference's `ActorCritic` agent (th_rl/agents.py:222-330) for G games: Reinforce's policy
+    network plus the value head fc_v; train() = thrl_ac_train (needs the replayed next states)."""
+    value_head = True
+    _fn = dict(count="thrl_ac_param_count", init="thrl_ac_init", act="thrl_ac_act")
+
+    def train(self, price, action, reward, want_grad=False, next_price=None):
+        torch = _torch()
+        if next_price is None:
+            raise ThrlError("ActorCriticBatch.train needs next_price (the replayed new_state)")
+        with torch.cuda.device(self.device):
+            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
+            d_a = self._dev(action, torch.int32).reshape(n, self.G)
+            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
+            d_n = self._dev(next_price, torch.float64).reshape(n, self.G)
+            d_p = d_p.reshape(n, self.G)
+            grad = torch.zeros_like(self.params) if want_grad else None
+            _lib.check(self.L.thrl_ac_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
+                                            self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a), self._p(d_r),
+                                            self._p(d_n), self.gamma, self.entropy, self.lr, self._p(grad),
+                                            self._stream()), "thrl_ac_train")
             torch.cuda.synchronize(self.device)
         self.step += 1
         return grad

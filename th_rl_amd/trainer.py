@@ -60,9 +60,9 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
 
     config, agents, environment = create_game(configpath)
     if not all(isinstance(a, (QTable, Reinforce)) for a in agents) or not isinstance(environment, NoisyPriceState):
-        raise NotImplementedError(
-            "train_one: the device path trains QTable and Reinforce agents on NoisyPriceState; "
-            "ActorCritic / CAC are not built yet (SURVEY.md section 8f)")
+        raise NotImplementedError(                      # (ActorCritic is a Reinforce subclass here)
+            "train_one: the device path trains QTable, Reinforce and ActorCritic agents on NoisyPriceState; "
+            "CAC is not built yet (SURVEY.md section 8f)")
     all_tabular = all(isinstance(a, QTable) for a in agents)
 
     training = config.get("training", {})
@@ -81,7 +81,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
                           seed=seed, game_offset=int(training.get("game_offset", 0)),
                           kernel=training.get("kernel", "auto"), sweep=training.get("sweep", None))
     else:
-        # games with neural agents: the unfused batched operator loop (mixed.py)
+        # games with neural agents: fused episode kernel + batched network updates (mixed.py)
         from th_rl_amd.mixed import MixedGameBatch
         if resume:
             raise NotImplementedError("resume is available for all-QTable configs only")
