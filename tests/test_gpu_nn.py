@@ -381,3 +381,31 @@ def test_actorcritic_game_fused_equals_operator_loop_and_trains(tmp_path):
     assert sorted(sd) == ["fc1.bias", "fc1.weight", "fc_pi.bias", "fc_pi.weight", "fc_v.bias", "fc_v.weight"]
     assert sd["fc_v.weight"].shape == (1, 256) and abs(float(sd["fc_v.bias"]) - 1000.0) < 0.01
     assert (tmp_path / "run" / "0.npy").exists() and (tmp_path / "run" / "log.csv").exists()
+
+
+def test_three_agent_mix_and_unsupported_fallback():
+    """Three agents (QTable, Reinforce, QTable with its own grid) take the fused kernel's NA=8
+    instantiation: bit-identical to the operator loop.  Three NEURAL agents are beyond the fused
+    kernel (two networks fit in registers): fused=True raises thrl_err -3, the default falls back."""
+    from th_rl_amd._lib import ThrlError
+    from th_rl_amd.mixed import MixedGameBatch
+    T = 24
+    env = dict(ENV, max_steps=T, nplayers=3, noise_prob=0.2)
+    q0 = dict(Q_AGENT, min_memory=T)
+    q2 = dict(Q_AGENT, min_memory=2 * T, actions=11, states=50, alpha=0.2, action_range=[0.1, 0.3], capacity=100)
+    r = dict(R_AGENT, min_memory=2 * T, actions=17, entropy=0.01)
+    config = {"agents": [q0, r, q2], "environment": env}
+    a = MixedGameBatch(config, n_games=6, dtype="float32", seed=13).init_tables()
+    b = MixedGameBatch(config, n_games=6, dtype="float32", seed=13).init_tables()
+    ra, rb = a.run(5, fused=True), b.run(5, fused=False)
+    assert ra["kernel"] == "mixed-fused" and a.nn[1].step == b.nn[1].step == 2
+    assert np.array_equal(ra["game_reward_log"], rb["game_reward_log"])
+    assert np.array_equal(ra["game_action_log"], rb["game_action_log"])
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy()) and np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy()) and a.eps == b.eps and a.count == b.count
+    assert np.array_equal(a.nn[1].params.cpu().numpy(), b.nn[1].params.cpu().numpy())
+    three = {"agents": [dict(r), dict(r), dict(r)], "environment": env}
+    c = MixedGameBatch(three, n_games=2, dtype="float32", seed=1).init_tables()
+    with pytest.raises(ThrlError, match="more than two neural agents"):
+        c.run(1, fused=True)
+    assert c.run(3)["kernel"] == "unfused" and c.nn[0].step == 1

@@ -12,7 +12,9 @@ KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wave"}
 
 
 class ThrlError(RuntimeError):
-    pass
+    code = None             # the negative thrl_err when the error came from the library
+
+ERR_UNSUPPORTED = -3
 
 
 class Cfg(ctypes.Structure):
@@ -167,7 +169,9 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().thrl_last_error().decode("utf-8", "replace")
-        raise ThrlError("%s failed (thrl_err %d): %s" % (what, rc, msg))
+        err = ThrlError("%s failed (thrl_err %d): %s" % (what, rc, msg))
+        err.code = rc
+        raise err
 
 
 # QTable.__init__ defaults (reference th_rl/agents.py:13-27) / NoisyPriceState (environments.py:5)

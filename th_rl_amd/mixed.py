@@ -152,9 +152,18 @@ class MixedGameBatch:
         idx = (torch.arange(n, device=self.device) + start) % cap
         return n, {k: v.index_select(0, idx).contiguous() for k, v in b.items()}
 
-    def run(self, n_episodes, fused=True):
-        """n_episodes for all games.  fused=True (default): thrl_mixed_episodes, one launch per run of
-        episodes between network updates; fused=False: the per-call operator loop (same results)."""
+    def run(self, n_episodes, fused=None):
+        """n_episodes for all games.  fused=True: thrl_mixed_episodes, one launch per run of episodes
+        between network updates; fused=False: the per-call operator loop (same results); None
+        (default): fused unless the library reports the configuration as unsupported by that kernel
+        (more than two neural agents, Q-tables beyond 64 KiB of LDS per game, > 64 actions)."""
+        if fused is None:
+            try:
+                return self._run_fused(int(n_episodes))
+            except ThrlError as e:
+                if e.code != _lib.ERR_UNSUPPORTED:
+                    raise
+                return self._run_unfused(int(n_episodes))      # nothing was launched: state is untouched
         if fused:
             return self._run_fused(int(n_episodes))
         return self._run_unfused(int(n_episodes))
