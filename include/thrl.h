@@ -242,6 +242,28 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
                   const double* reward, const double* next_price, double gamma, double entropy_coef,
                   double lr, float* grad_out, void* stream);
 /*
+ * `CAC`, the continuous actor-critic (agents.py:333-442): fc1 (1 -> 256) and three 256 -> 1 heads,
+ * mu = 4*tanh(fc_mu h), std = softplus(fc_std h), v = fc_v h.  THRL_CAC_PARAMS floats per game:
+ *   [fc1.weight 256 | fc1.bias 256 | fc_mu.weight 256 | fc_mu.bias | fc_std.weight 256 | fc_std.bias |
+ *    fc_v.weight 256 | fc_v.bias]
+ * thrl_cac_act = pi + sample_action (:360-381): a = mu + std*z, z from u1,u2 [G] by Box-Muller,
+ *   action = sigmoid(a) in (0,1) (float32 [G]); scale is action*(hi-lo)+lo (:371-375).
+ *   u1 == NULL gives the MEAN action sigmoid(mu): the reference's get_action (:383-387) builds
+ *   Normal(mu, 0), which torch rejects (ValueError, recorded in tests/golden/g9_cac.npz), so its play
+ *   path cannot run; the mean action is what it intends.  mu/std/v outputs are optional.
+ * thrl_cac_train = train_net (:389-416) AS THE REFERENCE EXECUTES IT: rewards / actions [N] against
+ *   mu / std / v [N,1] broadcast to [N,N] -- advantage[i,j] = r_j + gamma*v'_i - v_i and
+ *   log_prob[i,j] = log N(logit(a_j); mu_i, std_i); loss = mean_ij(advantage^2 - log_prob*advantage)
+ *   + entropy_coef*(-mean entropy); clip 1.0; Adam.  action [n][G] float32 as stored by the trainer.
+ */
+#define THRL_CAC_PARAMS 1283
+int thrl_cac_init(int n_games, float* params, uint64_t seed, uint64_t game_offset, int agent, void* stream);
+int thrl_cac_act(int n_games, const float* params, const double* price, const double* u1, const double* u2,
+                 float* action_out, float* mu_out, float* std_out, float* v_out, void* stream);
+int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
+                   const double* price, const float* action, const double* reward, const double* next_price,
+                   double gamma, double entropy_coef, double lr, float* grad_out, void* stream);
+/*
  * Fused episodes for games whose agents are any mix of QTable and Reinforce (the pairing of the
  * reference's example configs): trainer.train_one's loop (trainer.py:46-70) with QTable.train_net
  * inside the kernel.  Reinforce / ActorCritic transitions go to that agent's replay buffer; the
@@ -249,7 +271,7 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
  * network update falls inside one call.  Replay buffers are rings [buf_len][G] per agent.
  */
 typedef struct {
-    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic       */
+    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic (3 = CAC: THRL_ERR_UNSUPPORTED, use the operators) */
     const float* nn_params[THRL_MAXA];   /* device [G][P] for the neural agents              */
     double*  buf_price[THRL_MAXA];       /* device [buf_len][G] state  (trainer.py:62)       */
     int32_t* buf_action[THRL_MAXA];
@@ -264,10 +286,12 @@ int thrl_mixed_episodes(const thrl_cfg* cfg, thrl_mixed* mx, void* q, int32_t* c
                         thrl_run* run, double* game_reward_log, double* game_action_log, void* stream);
 
 /* Philox draws for one lockstep step of a caller-driven loop: u [N][G] f64 uniforms and
- * choice [N][G] int8 indices (agents.py:81-82), optionally the env's two noise draws [G]
+ * choice [N][G] int8 indices (agents.py:81-82), optionally u2 [N][G] (the word behind `choice` as a
+ * uniform: CAC's second Box-Muller input) and the env's two noise draws [G]
  * (environments.py:28-29); same streams/counters as thrl_qtable_episodes uses internally. */
 int thrl_op_draws(const thrl_cfg* cfg, uint64_t seed, uint64_t game_offset, uint64_t episode, int32_t step,
-                  double* u_out, int8_t* choice_out, double* noise_u_out, double* noise_a_out, void* stream);
+                  double* u_out, int8_t* choice_out, double* u2_out, double* noise_u_out, double* noise_a_out,
+                  void* stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,57 @@ def main():
         PARAMS = ["fc1.weight", "fc1.bias", "fc_pi.weight", "fc_pi.bias"] + \
                  (["fc_v.weight", "fc_v.bias"] if cls == "ActorCritic" else [])
         one(cls, fname, cases)
+    cac()
+
+
+def cac():
+    """G9: the reference's CAC agent (agents.py:333-442).  pi()/v() on probe states, two train_net()
+    calls on 1,000 transitions each (actions in (0,1) as sample_action returns them)."""
+    names = ["fc1.weight", "fc1.bias", "fc_mu.weight", "fc_mu.bias", "fc_std.weight", "fc_std.bias",
+             "fc_v.weight", "fc_v.bias"]
+    fl = lambda d: numpy.concatenate([d[k].detach().numpy().ravel() for k in names]).astype("float32")
+    out = {}
+    for tag, kw in (("cfg", dict(gamma=0.98, states=1, action_range=[0.2, 0.4])),
+                    ("ent", dict(gamma=0.9, states=1, action_range=[0.2, 0.4], entropy=0.01))):
+        numpy.random.seed(5); random.seed(5); torch.manual_seed(5)
+        ag = ref_agents.CAC(**kw)
+        out[tag + "_w0"] = fl(ag.state_dict())
+        probe = numpy.linspace(2.0, 6.0, 9)
+        out[tag + "_probe_price"] = probe
+        rs = numpy.random.RandomState(17)
+        for call in range(2):
+            price = rs.randint(20, 61, size=1001) / 10.0
+            action = rs.uniform(0.02, 0.98, size=1000).astype("float32")
+            reward = rs.uniform(5, 15, size=1000)
+            for t in range(1000):
+                ag.memory.append(numpy.array([price[t]]), float(action[t]), float(reward[t]), True,
+                                 numpy.array([price[t + 1]]))
+            ag.train_net()
+            named = dict(ag.named_parameters())
+            out["%s_c%d_price" % (tag, call)] = price
+            out["%s_c%d_action" % (tag, call)] = action
+            out["%s_c%d_reward" % (tag, call)] = reward
+            out["%s_c%d_grad" % (tag, call)] = numpy.concatenate([named[k].grad.numpy().ravel() for k in names]).astype("float32")
+            st = ag.optimizer.state
+            out["%s_c%d_m" % (tag, call)] = numpy.concatenate([st[named[k]]["exp_avg"].numpy().ravel() for k in names]).astype("float32")
+            out["%s_c%d_v" % (tag, call)] = numpy.concatenate([st[named[k]]["exp_avg_sq"].numpy().ravel() for k in names]).astype("float32")
+            out["%s_c%d_w" % (tag, call)] = fl(ag.state_dict())
+        with torch.no_grad():
+            pv = [ag.pi(torch.from_numpy(numpy.array([q]).astype("float32"))) for q in probe]
+            out[tag + "_probe_mu2"] = numpy.array([float(a[0]) for a in pv], "float32")
+            out[tag + "_probe_std2"] = numpy.array([float(a[1]) for a in pv], "float32")
+            out[tag + "_probe_value2"] = numpy.array(
+                [float(ag.v(torch.from_numpy(numpy.array([q]).astype("float32")))) for q in probe], "float32")
+        out[tag + "_scale"] = numpy.array([ag.scale(k) for k in (0.0, 0.25, 0.7311, 1.0)])
+        try:
+            ag.get_action(numpy.array([3.4]))
+            out[tag + "_get_action_raises"] = numpy.array(0)
+        except Exception as e:                       # noqa: BLE001  (recorded as data)
+            out[tag + "_get_action_raises"] = numpy.array(1)
+            out[tag + "_get_action_error"] = numpy.array(type(e).__name__)
+    p = os.path.join(HERE, "g9_cac.npz")
+    numpy.savez_compressed(p, **out)
+    print("wrote", p, os.path.getsize(p))
 
 
 def one(cls, fname, cases):

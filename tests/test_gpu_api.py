@@ -187,16 +187,6 @@ def test_train_one_sweep(tmp_path):
         assert np.array_equal(ref.tables_numpy()[sl], b["q"].numpy()[sl])
 
 
-def test_train_one_rejects_unbuilt_neural_agents(tmp_path):
-    from th_rl_amd import trainer
-    cfgp = tmp_path / "cfg.json"
-    c = _config(2)
-    c["agents"][1] = {"name": "CAC", "gamma": 0.995, "states": 1, "action_range": [0.2, 0.4]}
-    cfgp.write_text(json.dumps(c))
-    with pytest.raises(NotImplementedError, match="CAC"):
-        trainer.train_one(str(tmp_path / "r"), str(cfgp))
-
-
 def test_protocol_env_step_matches_reference_grid():
     """NoisyPriceState.step / QTable.scale / encode through the device operators ==
     the reference on the whole 21x21 action grid (golden G1), incl. noise branch."""

@@ -78,7 +78,9 @@ SYMBOLS = [
     "thrl_op_env_step", "thrl_op_td_update",
     "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
     "thrl_mixed_episodes", "thrl_ac_param_count", "thrl_ac_init", "thrl_ac_act", "thrl_ac_train",
+    "thrl_cac_init", "thrl_cac_act", "thrl_cac_train",
 ]
+CAC_PARAMS = 1283
 
 _lib = None
 
@@ -148,7 +150,14 @@ def load():
     L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp,
                                           dbl, dbl, dbl, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
-    L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp]
+    L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]
+    L.thrl_cac_init.restype = ctypes.c_int
+    L.thrl_cac_init.argtypes = [ctypes.c_int, vp, u64, u64, ctypes.c_int, vp]
+    L.thrl_cac_act.restype = ctypes.c_int
+    L.thrl_cac_act.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.thrl_cac_train.restype = ctypes.c_int
+    L.thrl_cac_train.argtypes = [ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
+                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
     L.thrl_ac_param_count.restype = ctypes.c_size_t
     L.thrl_ac_param_count.argtypes = [ctypes.c_int]
     L.thrl_ac_init.restype = ctypes.c_int

@@ -134,11 +134,11 @@ class QTable:
 
 
 class _NeuralAgentBase(nn.Module):
-    """Common part of the reference's torch agents: parameters, memory, scale, save/load.  Reinforce and
-    ActorCritic act and learn on the device; CAC is a constructor-compatible shell (configs load)."""
+    """Common part of the reference's torch agents: parameters, memory, scale, save/load.  The torch
+    modules only HOLD the parameters (state_dict / save / load keep the reference's format); acting
+    and learning run on the device in the subclasses."""
 
-    _scope_note = ("CAC (continuous actions) is not built yet (SURVEY.md section 8f, rank 3); "
-                   "QTable, Reinforce and ActorCritic agents train on the device")
+    _scope_note = "this agent class does not act or learn on its own; use Reinforce, ActorCritic or CAC"
 
     def _common(self, actions, action_range, gamma, buffer, capacity, min_memory, entropy):
         self.gamma = gamma
@@ -296,12 +296,81 @@ class ActorCritic(Reinforce):
 
 
 class CAC(_NeuralAgentBase):
-    def __init__(self, states=4, actions=2, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer",
-                 capacity=50000, min_memory=1000, entropy=0, **kwargs):
+    """The reference's continuous actor-critic (agents.py:333-442): actions are floats in (0,1).
+    Acting and train_net run on the device (thrl_cac_act / thrl_cac_train).  get_action returns the
+    mean action sigmoid(mu): the reference's own get_action builds Normal(mu, 0) and raises
+    ValueError under current torch (recorded in tests/golden/g9_cac.npz)."""
+
+    def __init__(self, states=4, action_range=[0, 1], gamma=0.98, buffer="ReplayBuffer", capacity=50000,
+                 min_memory=1000, entropy=0, **kwargs):
         super().__init__()
+        self.data = []
         self.fc1 = nn.Linear(states, 256)
         self.fc_mu = nn.Linear(256, 1)
         self.fc_std = nn.Linear(256, 1)
         self.fc_v = nn.Linear(256, 1)
         self.optimizer = optim.Adam(self.parameters(), lr=2e-4)
-        self._common(actions, action_range, gamma, buffer, capacity, min_memory, entropy)
+        self._common(None, action_range, gamma, buffer, capacity, min_memory, entropy)
+        del self.actions                                       # the reference's CAC has no such attribute
+        self.cast = [torch.float, torch.float, torch.float, torch.float, torch.float]
+        self.states = states
+        self._rb = None
+
+    _layers = ("fc1", "fc_mu", "fc_std", "fc_v")
+
+    def flat_params(self):
+        parts = []
+        for name in self._layers:
+            layer = getattr(self, name)
+            parts += [layer.weight.detach().numpy().ravel(), layer.bias.detach().numpy().ravel()]
+        return numpy.concatenate(parts).astype("float32")
+
+    def set_flat_params(self, w):
+        w = numpy.asarray(w, "float32")
+        o = 0
+        with torch.no_grad():
+            for name in self._layers:
+                layer = getattr(self, name)
+                for t in (layer.weight, layer.bias):
+                    n = t.numel()
+                    t.copy_(torch.from_numpy(w[o:o + n].reshape(tuple(t.shape)).copy()))
+                    o += n
+
+    def _device(self):
+        if self.states != 1:
+            raise _lib.ThrlError("CAC on the device needs states == 1")
+        if self._rb is None:
+            from .nn import CACBatch
+            self._rb = CACBatch(1, gamma=self.gamma, entropy=self.entropy)
+        self._rb.gamma, self._rb.entropy = float(self.gamma), float(self.entropy)
+        self._rb.set_params(self.flat_params())
+        return self._rb
+
+    def scale(self, action):
+        return action * (self.action_range[1] - self.action_range[0]) + self.action_range[0]
+
+    def pi(self, x):
+        _, (mu, std, _) = self._device().act(numpy.asarray(x, dtype="float64").reshape(1), want_heads=True)
+        return mu.cpu(), std.cpu()
+
+    def v(self, x):
+        _, (_, _, v) = self._device().act(numpy.asarray(x, dtype="float64").reshape(1), want_heads=True)
+        return v.cpu()
+
+    def sample_action(self, state):
+        u1, u2 = float(torch.rand(())), float(torch.rand(()))  # Box-Muller inputs for Normal(mu, std).sample()
+        return float(self._device().act(numpy.asarray(state, dtype="float64").reshape(1), u1=[u1], u2=[u2]).cpu()[0])
+
+    def get_action(self, state):
+        return float(self._device().act(numpy.asarray(state, dtype="float64").reshape(1)).cpu()[0])
+
+    def train_net(self):
+        if len(self.memory) >= self.min_memory:
+            states, actions, rewards, done, s_prime = self.memory.replay()
+            n = len(actions)
+            rb = self._device()
+            rb.train(numpy.array(states, dtype="float64").reshape(n, 1), numpy.array(actions, dtype="float32").reshape(n, 1),
+                     numpy.array(rewards, dtype="float64").reshape(n, 1),
+                     next_price=numpy.array(s_prime, dtype="float64").reshape(n, 1))
+            self.set_flat_params(rb.params.cpu().numpy()[0])
+            self.memory.empty()

@@ -607,6 +607,7 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
     a.game_reward_log = game_reward_log; a.game_action_log = game_action_log;
     a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
     for (int i = 0; i < c->n_agents; i++) {
+        if (mx->kind[i] == 3) return fail(THRL_ERR_UNSUPPORTED, "agent %d: CAC agents run through the operator loop", i);
         if (mx->kind[i] < 0 || mx->kind[i] > 2) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
         if (mx->kind[i] != 0 && (!mx->nn_params[i] || c->n_actions[i] > 32))
             return fail(THRL_ERR_NULL, "agent %d: a neural agent needs nn_params and actions <= 32", i);
@@ -644,8 +645,39 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
     return THRL_OK;
 }
 
+int thrl_cac_init(int n_games, float* params, uint64_t seed, uint64_t game_offset, int agent, void* stream) {
+    if (n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", n_games);
+    if (!params) return fail(THRL_ERR_NULL, "params is NULL");
+    const int e = launch_cac_init(n_games, params, seed, game_offset, agent, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_cac_init launch") : THRL_OK;
+}
+
+int thrl_cac_act(int n_games, const float* params, const double* price, const double* u1, const double* u2,
+                 float* action_out, float* mu_out, float* std_out, float* v_out, void* stream) {
+    if (n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", n_games);
+    if (!params || !price || !action_out) return fail(THRL_ERR_NULL, "params/price/action_out is NULL");
+    if ((u1 == nullptr) != (u2 == nullptr)) return fail(THRL_ERR_NULL, "u1 and u2 must both be given or both NULL");
+    const int e = launch_cac_act(n_games, params, price, u1, u2, action_out, mu_out, std_out, v_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_cac_act launch") : THRL_OK;
+}
+
+int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
+                   const double* price, const float* action, const double* reward, const double* next_price,
+                   double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+    if (n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", n_games);
+    if (!params || !adam_m || !adam_v || !price || !action || !reward || !next_price)
+        return fail(THRL_ERR_NULL, "a required pointer is NULL");
+    if (n < 2 || cac_train_lds_bytes(n) > 160 * 1024)
+        return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions: need 2 <= n and the batch in LDS (n <= ~5600)", n);
+    if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
+    const int e = launch_cac_train(n_games, params, adam_m, adam_v, step, n, price, action, reward, next_price,
+                                   (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+    return e ? hip_fail(e, "k_cac_train launch") : THRL_OK;
+}
+
 int thrl_op_draws(const thrl_cfg* c, uint64_t seed, uint64_t game_offset, uint64_t episode, int32_t step,
-                  double* u_out, int8_t* choice_out, double* noise_u_out, double* noise_a_out, void* stream) {
+                  double* u_out, int8_t* choice_out, double* u2_out, double* noise_u_out, double* noise_a_out,
+                  void* stream) {
     int rc = validate(c);
     if (rc) return rc;
     if (!u_out || !choice_out) return fail(THRL_ERR_NULL, "u_out/choice_out is NULL");
@@ -653,7 +685,7 @@ int thrl_op_draws(const thrl_cfg* c, uint64_t seed, uint64_t game_offset, uint64
     int32_t nA[THRL_MAXA];
     for (int i = 0; i < THRL_MAXA; i++) nA[i] = i < c->n_agents ? c->n_actions[i] : 1;
     const int e = launch_op_draws(c->n_games, c->n_agents, seed, game_offset, (uint32_t)episode, (uint32_t)step,
-                                  c->env_a, c->env_a * 0.7, nA, u_out, choice_out, noise_u_out, noise_a_out,
+                                  c->env_a, c->env_a * 0.7, nA, u_out, choice_out, u2_out, noise_u_out, noise_a_out,
                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_op_draws launch") : THRL_OK;
 }

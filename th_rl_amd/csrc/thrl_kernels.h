@@ -147,7 +147,16 @@ int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, i
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
                     float* grad,
                     hipStream_t s);
+// ---- continuous actor-critic agent CAC (thrl_cac.hip)
+int launch_cac_init(int G, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s);
+int launch_cac_act(int G, const float* params, const double* price, const double* u1, const double* u2, float* action,
+                   float* mu, float* sd, float* v, hipStream_t s);
+size_t cac_train_lds_bytes(int N);
+int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, const double* price, const float* action,
+                     const double* reward, const double* nprice, float gamma, float ent, float lr, float* grad,
+                     hipStream_t s);
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
-                    double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* nu, double* na, hipStream_t s);
+                    double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* u2, double* nu, double* na,
+                    hipStream_t s);
 
 }  // namespace thrl

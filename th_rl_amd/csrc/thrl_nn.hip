@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
 __global__ void __launch_bounds__(256) k_op_draws(int G, int N, uint64_t seed, uint64_t game_offset,
         uint32_t episode, uint32_t step, double env_a, double noise_lo, int32_t nA0, int32_t nA1, int32_t nA2,
         int32_t nA3, int32_t nA4, int32_t nA5, int32_t nA6, int32_t nA7, double* u_out, int8_t* choice_out,
-        double* noise_u_out, double* noise_a_out) {
+        double* u2_out, double* noise_u_out, double* noise_a_out) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     const int32_t nA[8] = {nA0, nA1, nA2, nA3, nA4, nA5, nA6, nA7};
@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) k_op_draws(int G, int N, uint64_t seed, u
         const uint32_t xu = (i & 1) ? x.z : x.x, xc = (i & 1) ? x.w : x.y;
         u_out[(size_t)i * G + g] = u01_32(xu);
         choice_out[(size_t)i * G + g] = (int8_t)__umulhi(xc, (uint32_t)nA[i]);
+        if (u2_out) u2_out[(size_t)i * G + g] = u01_32(xc);      // the second word as a uniform (CAC's Box-Muller)
     }
     if (noise_u_out) {
         const u32x4 xn = draw(seed, gid, episode, step, kStreamNoise);
@@ -398,9 +399,10 @@ int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, i
     return (int)hipGetLastError();
 }
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
-                    double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* nu, double* na, hipStream_t s) {
+                    double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* u2, double* nu, double* na,
+                    hipStream_t s) {
     hipLaunchKernelGGL(k_op_draws, dim3((G + 255) / 256), dim3(256), 0, s, G, N, seed, off, episode, step, env_a,
-                       noise_lo, nA[0], nA[1], nA[2], nA[3], nA[4], nA[5], nA[6], nA[7], u, ch, nu, na);
+                       noise_lo, nA[0], nA[1], nA[2], nA[3], nA[4], nA[5], nA[6], nA[7], u, ch, u2, nu, na);
     return (int)hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import ThrlError
 from .batched import _require_gpu, _torch
-from .nn import ActorCriticBatch, ReinforceBatch
+from .nn import ActorCriticBatch, CACBatch, ReinforceBatch
 
 NN_DEFAULTS = dict(states=4, actions=2, action_range=[0, 1], gamma=0.98, capacity=50000, min_memory=1000,
                    entropy=0)
@@ -36,8 +36,9 @@ class MixedGameBatch:
         self.dtype = {"float32": 0, "float64": 1}[str(dtype)]
         self.kinds = [a.get("name", "QTable") for a in config["agents"]]
         for k in self.kinds:
-            if k not in ("QTable", "Reinforce", "ActorCritic"):
-                raise NotImplementedError("device path: agent %r is not supported (QTable, Reinforce, ActorCritic)" % k)
+            if k not in ("QTable", "Reinforce", "ActorCritic", "CAC"):
+                raise NotImplementedError("device path: agent %r is not supported "
+                                          "(QTable, Reinforce, ActorCritic, CAC)" % k)
         # thrl_cfg for the operators: a Reinforce agent occupies a dummy 2-row table slot
         as_q = []
         self.nn_cfg = {}
@@ -49,6 +50,8 @@ class MixedGameBatch:
                 if int(p["states"]) != 1:
                     raise ThrlError("%s on the device needs states == 1 (the env state is one number)" % self.kinds[i])
                 self.nn_cfg[i] = p
+                if self.kinds[i] == "CAC":
+                    p["actions"] = 2                 # continuous: the table slot is a placeholder
                 as_q.append(dict(name="QTable", states=1, actions=int(p["actions"]), action_range=p["action_range"],
                                  capacity=1, min_memory=1))
         qconf = {"agents": as_q, "environment": config["environment"]}
@@ -63,7 +66,8 @@ class MixedGameBatch:
             self.q = torch.zeros((self.G, self.stride), dtype=tdt, device=self.device)
             self.counter = torch.zeros((self.G, self.stride), dtype=torch.int32, device=self.device)
             self.state = torch.zeros((self.G,), dtype=torch.float64, device=self.device)
-        self.nn = {i: (ActorCriticBatch if self.kinds[i] == "ActorCritic" else ReinforceBatch)(
+        classes = {"Reinforce": ReinforceBatch, "ActorCritic": ActorCriticBatch, "CAC": CACBatch}
+        self.nn = {i: classes[self.kinds[i]](
             self.G, actions=int(p["actions"]), gamma=float(p["gamma"]), entropy=float(p["entropy"]), device=device,
             seed=seed, game_offset=game_offset, agent_index=i) for i, p in self.nn_cfg.items()}
         self.cap = [int(self.cfg.capacity[i]) if self.kinds[i] == "QTable" else int(self.nn_cfg[i]["capacity"])
@@ -75,10 +79,11 @@ class MixedGameBatch:
                         for i in range(self.N)]
         with torch.cuda.device(self.device):
             self.buf = [dict(price=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
-                             action=torch.zeros((max(n, 1), self.G), dtype=torch.int32, device=self.device),
+                             action=torch.zeros((max(n, 1), self.G), device=self.device,
+                                                dtype=torch.float32 if self.kinds[i] == "CAC" else torch.int32),
                              reward=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
                              nprice=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device))
-                        for n in self.buf_len]
+                        for i, n in enumerate(self.buf_len)]
         self.count = [0] * self.N            # appends since the last empty()
         self.episode = 0
         self.initialized = False
@@ -189,7 +194,7 @@ class MixedGameBatch:
                         k = min(k, need)
                 mx = _lib.Mixed()
                 for i in range(N):
-                    mx.kind[i] = {"QTable": 0, "Reinforce": 1, "ActorCritic": 2}[self.kinds[i]]
+                    mx.kind[i] = {"QTable": 0, "Reinforce": 1, "ActorCritic": 2, "CAC": 3}[self.kinds[i]]
                     if self.kinds[i] != "QTable":
                         mx.nn_params[i] = self.nn[i].params.data_ptr()
                     b = self.buf[i]
@@ -235,6 +240,9 @@ class MixedGameBatch:
             alog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
             u = torch.zeros((N, G), dtype=torch.float64, device=self.device)
             ch = torch.zeros((N, G), dtype=torch.int8, device=self.device)
+            has_cac = "CAC" in self.kinds
+            u2 = torch.zeros((N, G), dtype=torch.float64, device=self.device) if has_cac else None
+            acts_f = torch.zeros((N, G), dtype=torch.float32, device=self.device) if has_cac else None
             nu = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
             na = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
             acts = torch.zeros((N, G), dtype=torch.int32, device=self.device)
@@ -248,7 +256,7 @@ class MixedGameBatch:
             for e in range(E):
                 for t in range(T):
                     _lib.check(L.thrl_op_draws(cfg, self.seed, self.game_offset, self.episode, t, self._p(u), self._p(ch),
-                                               self._p(nu), self._p(na), self._stream()), "thrl_op_draws")
+                                               self._p(u2), self._p(nu), self._p(na), self._stream()), "thrl_op_draws")
                     for i in range(N):
                         if self.kinds[i] == "QTable":
                             _lib.check(L.thrl_op_sample_action(cfg, i, self._p(self.q), self._p(price), self.eps[i],
@@ -256,6 +264,11 @@ class MixedGameBatch:
                                                                self._stream()), "thrl_op_sample_action")
                             _lib.check(L.thrl_op_scale(cfg, i, self._p(acts[i]), self._p(scaled[i]), self._stream()),
                                        "thrl_op_scale")
+                        elif self.kinds[i] == "CAC":
+                            lo, hi = [float(x) for x in self.nn_cfg[i]["action_range"]]
+                            acts_f[i].copy_(self.nn[i].act(price, u1=u[i], u2=u2[i]))
+                            # CAC.scale (agents.py:371-375): action * (hi - lo) + lo on the Python float
+                            scaled[i].copy_(acts_f[i].to(torch.float64) * (hi - lo) + lo)
                         else:
                             rb = self.nn[i]
                             acts[i].copy_(rb.act(price, u=u[i]))
@@ -266,7 +279,7 @@ class MixedGameBatch:
                     _lib.check(L.thrl_op_env_step(cfg, self._p(scaled), self._p(nu), self._p(na), self._p(nprice),
                                                   self._p(reward), self._stream()), "thrl_op_env_step")
                     for i in range(N):
-                        self._append(i, price, acts[i], reward[i], nprice)
+                        self._append(i, price, acts_f[i] if self.kinds[i] == "CAC" else acts[i], reward[i], nprice)
                     rlog[e] += torch.div(reward, T_t)           # trainer.py:65
                     alog[e] += torch.div(scaled, T_t)           # trainer.py:66
                     price = nprice.clone()

@@ -113,3 +113,70 @@ class ActorCriticBatch(ReinforceBatch):
             torch.cuda.synchronize(self.device)
         self.step += 1
         return grad
+
+
+class CACBatch:
+    """The reference's continuous actor-critic `CAC` (th_rl/agents.py:333-442) for G games: 1283
+    parameters per game, actions are float32 in (0,1).  act(u1=None) returns the mean action
+    sigmoid(mu) -- the reference's get_action raises under current torch (include/thrl.h)."""
+    value_head = True
+
+    def __init__(self, n_games, gamma=0.98, entropy=0.0, lr=2e-4, device="cuda:0", seed=0, game_offset=0,
+                 agent_index=0, **_):
+        self.L = _lib.load()
+        torch = _torch()
+        self.device = _require_gpu(device)
+        self.G, self.P = int(n_games), _lib.CAC_PARAMS
+        self.gamma, self.entropy, self.lr = float(gamma), float(entropy), float(lr)
+        self.seed, self.game_offset, self.agent_index = int(seed), int(game_offset), int(agent_index)
+        with torch.cuda.device(self.device):
+            self.params = torch.zeros((self.G, self.P), dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        self.step = 0
+
+    _stream = ReinforceBatch._stream
+    _p = staticmethod(ReinforceBatch._p)
+    _dev = ReinforceBatch._dev
+    set_params = ReinforceBatch.set_params
+
+    def init(self):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.thrl_cac_init(self.G, self._p(self.params), self.seed, self.game_offset, self.agent_index,
+                                            self._stream()), "thrl_cac_init")
+        self.adam_m.zero_(); self.adam_v.zero_(); self.step = 0
+        return self
+
+    def act(self, price, u1=None, u2=None, want_heads=False):
+        """actions float32 [G] in (0,1) (device tensor); want_heads also returns (mu, std, v)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            d_price = self._dev(price, torch.float64).reshape(self.G)
+            d_u1 = None if u1 is None else self._dev(u1, torch.float64).reshape(self.G)
+            d_u2 = None if u2 is None else self._dev(u2, torch.float64).reshape(self.G)
+            out = torch.zeros((self.G,), dtype=torch.float32, device=self.device)
+            heads = [torch.zeros_like(out) for _ in range(3)] if want_heads else [None] * 3
+            _lib.check(self.L.thrl_cac_act(self.G, self._p(self.params), self._p(d_price), self._p(d_u1), self._p(d_u2),
+                                           self._p(out), self._p(heads[0]), self._p(heads[1]), self._p(heads[2]),
+                                           self._stream()), "thrl_cac_act")
+        return (out, heads) if want_heads else out
+
+    def train(self, price, action, reward, want_grad=False, next_price=None):
+        torch = _torch()
+        if next_price is None:
+            raise ThrlError("CACBatch.train needs next_price (the replayed new_state)")
+        with torch.cuda.device(self.device):
+            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
+            d_a = self._dev(action, torch.float32).reshape(n, self.G)
+            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
+            d_n = self._dev(next_price, torch.float64).reshape(n, self.G)
+            d_p = d_p.reshape(n, self.G)
+            grad = torch.zeros_like(self.params) if want_grad else None
+            _lib.check(self.L.thrl_cac_train(self.G, self._p(self.params), self._p(self.adam_m), self._p(self.adam_v),
+                                             self.step, n, self._p(d_p), self._p(d_a), self._p(d_r), self._p(d_n),
+                                             self.gamma, self.entropy, self.lr, self._p(grad), self._stream()),
+                       "thrl_cac_train")
+            torch.cuda.synchronize(self.device)
+        self.step += 1
+        return grad

@@ -59,10 +59,9 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         os.mkdir(os.path.join(exp_path))
 
     config, agents, environment = create_game(configpath)
-    if not all(isinstance(a, (QTable, Reinforce)) for a in agents) or not isinstance(environment, NoisyPriceState):
+    if not all(isinstance(a, (QTable, Reinforce, CAC)) for a in agents) or not isinstance(environment, NoisyPriceState):
         raise NotImplementedError(                      # (ActorCritic is a Reinforce subclass here)
-            "train_one: the device path trains QTable, Reinforce and ActorCritic agents on NoisyPriceState; "
-            "CAC is not built yet (SURVEY.md section 8f)")
+            "train_one: the device path trains QTable, Reinforce, ActorCritic and CAC agents on NoisyPriceState")
     all_tabular = all(isinstance(a, QTable) for a in agents)
 
     training = config.get("training", {})
