@@ -301,3 +301,21 @@ def test_play_game_protocol_equals_batched_kernel():
     mr, ma = utils.play_game_batched(gb, iters=1, state0=st0)
     np.testing.assert_allclose(mr[0, :, 1], rewards[:15].mean(axis=0), rtol=1e-13)
     np.testing.assert_allclose(ma[0, :, 1], actions[:15].mean(axis=0), rtol=1e-13)
+
+
+def test_stored_reference_run_plays_the_same_greedy_game():
+    """The agents the reference ships trained (QTable + Reinforce state_dict) loaded through
+    utils.load_experiment and played through utils.play_game on the device == the game the
+    reference's own play_game plays with them (fixture G10, recorded by running the reference):
+    every scaled action and every reward of three 100-step games, bit for bit."""
+    from th_rl_amd.utils import load_experiment, play_game
+    loc = os.path.join(GOLDEN, "ref_run_example_config")
+    d = np.load(os.path.join(GOLDEN, "g10_stored_run.npz"))
+    config, agents, env, _, _ = load_experiment(loc)
+    for seed in (0, 1, 2):
+        np.random.seed(seed)
+        env.episode = 0
+        acts, rews = play_game(agents, env, iters=1)
+        assert acts.shape == (100, 2) and rews.shape == (100, 2)
+        assert np.array_equal(acts, d["play%d_actions" % seed]), seed
+        assert np.array_equal(rews, d["play%d_rewards" % seed]), seed

@@ -225,3 +225,24 @@ def test_two_rank_seed_sharding_over_gloo():
     tab, cnt, st = O.init(cfg, seed=7)
     out = O.episodes(cfg, tab, cnt, st, eps, O.Memory(cfg), E, seed=7)
     np.testing.assert_allclose(merged, out["reward_log"], rtol=1e-13)
+
+
+def test_load_experiment_reads_the_run_the_reference_ships():
+    """tests/golden/ref_run_example_config = the data files of th_rl/some_path/runs/example_config/0
+    (QTable vs Reinforce, 20,000 epochs; log.csv cut to its last 200 rows).  load_experiment
+    (utils.py:12-24) must read them unchanged: table / counter arrays, the torch state_dict of the
+    Reinforce agent (loaded with weights_only=True), the log columns."""
+    import torch
+    from th_rl_amd.utils import load_experiment
+    loc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_run_example_config")
+    config, agents, env, actions, rewards = load_experiment(loc)
+    assert [type(a).__name__ for a in agents] == ["QTable", "Reinforce"] and type(env).__name__ == "NoisyPriceState"
+    assert np.array_equal(agents[0].table, np.load(os.path.join(loc, "0.npy"))) and agents[0].table.shape == (101, 21)
+    assert agents[0].counter.sum() == 2000000.0              # 20,000 epochs x 100 steps
+    sd = torch.load(os.path.join(loc, "1"), weights_only=True)
+    assert sorted(sd) == ["fc1.bias", "fc1.weight", "fc_pi.bias", "fc_pi.weight"]
+    for k, v in agents[1].state_dict().items():
+        assert torch.equal(v, sd[k])
+    assert np.array_equal(agents[1].flat_params()[:256], sd["fc1.weight"].numpy().ravel())
+    assert list(actions.columns) == ["QTable0", "Reinforce1"] and actions.shape == rewards.shape == (201, 2)
+    assert config["training"]["epochs"] == 20000
