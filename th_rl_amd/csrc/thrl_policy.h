@@ -108,10 +108,12 @@ __device__ __forceinline__ float wave_sum32_transposed(float (&v)[32], int lane)
     return v[0] + dpp_f<kQuadXor1>(v[0]);
 }
 
+typedef float pf2 __attribute__((ext_vector_type(2)));
+
 template <int APAD>
 struct PolicyRegs {
     float w1[4], b1[4];
-    float w2[APAD][4];
+    pf2 w2[APAD / 2][4];       // fc_pi rows (2p, 2p+1) packed for v_pk_fma_f32
     float b2;                  // bias of action (lane >> 1)
 };
 
@@ -121,9 +123,11 @@ __device__ __forceinline__ void policy_load(PolicyRegs<APAD>& r, const float* __
 #pragma unroll
     for (int j = 0; j < 4; j++) { r.w1[j] = w[lane + 64 * j]; r.b1[j] = w[kH + lane + 64 * j]; }
 #pragma unroll
-    for (int k = 0; k < APAD; k++)
+    for (int p = 0; p < APAD / 2; p++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) r.w2[k][j] = k < A ? w[2 * kH + k * kH + lane + 64 * j] : 0.0f;
+        for (int j = 0; j < 4; j++)
+            r.w2[p][j] = pf2{2 * p < A ? w[2 * kH + (2 * p) * kH + lane + 64 * j] : 0.0f,
+                             2 * p + 1 < A ? w[2 * kH + (2 * p + 1) * kH + lane + 64 * j] : 0.0f};
     r.b2 = (lane >> 1) < A ? w[2 * kH + A * kH + (lane >> 1)] : 0.0f;
 }
 
@@ -137,13 +141,13 @@ __device__ __forceinline__ int policy_act(const PolicyRegs<APAD>& r, int A, floa
     for (int j = 0; j < 4; j++) h[j] = fmaxf(__fmaf_rn(r.w1[j], x, r.b1[j]), 0.0f);
     float v[32];
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        float s = 0.0f;
-        if (k < APAD) {
+    for (int p = 0; p < 16; p++) {
+        pf2 s = pf2{0.0f, 0.0f};
+        if (2 * p < APAD) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) s = __fmaf_rn(r.w2[k][j], h[j], s);
+            for (int j = 0; j < 4; j++) s = __builtin_elementwise_fma(r.w2[p][j], pf2{h[j], h[j]}, s);
         }
-        v[k] = s;
+        v[2 * p] = s.x; v[2 * p + 1] = s.y;
     }
     const float z = wave_sum32_transposed(v, lane) + r.b2;
     const int k = lane >> 1;
