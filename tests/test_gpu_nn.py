@@ -511,3 +511,28 @@ def test_qtable_vs_cac_game_and_train_one(tmp_path):
     ag.load(str(tmp_path / "run" / "1"))
     a = ag.get_action(np.array([3.4]))
     assert 0.0 < a < 1.0 and 0.2 < ag.scale(a) < 0.4 and 0.0 < ag.sample_action(np.array([3.4])) < 1.0
+
+
+def test_mixed_checkpoint_resume_is_exact(tmp_path):
+    """QTable vs ActorCritic: 9 episodes in one go == 3 episodes, save, load into a fresh batch,
+    6 more (tables, counters, state, epsilon, replay rings mid-fill, network + Adam state)."""
+    from th_rl_amd.mixed import MixedGameBatch
+    T = 20
+    ac = {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1, "action_range": [0.2, 0.4],
+          "min_memory": 70, "entropy": 0.01}
+    config = {"agents": [dict(Q_AGENT, min_memory=2 * T, capacity=50), ac], "environment": dict(ENV, max_steps=T)}
+    a = MixedGameBatch(config, n_games=7, dtype="float32", seed=17).init_tables()
+    ra = a.run(9)
+    b = MixedGameBatch(config, n_games=7, dtype="float32", seed=17).init_tables()
+    rb1 = b.run(3)
+    assert b.count == [20, 60] and b.nn[1].step == 0 and b.episode == 3      # both replay rings are mid-fill
+    b.save(str(tmp_path / "mixed.pt"))
+    c = MixedGameBatch(config, n_games=7, dtype="float32", seed=999)            # seed comes from the checkpoint
+    c.load(str(tmp_path / "mixed.pt"))
+    rc = c.run(6)
+    assert np.array_equal(np.concatenate([rb1["game_reward_log"], rc["game_reward_log"]]), ra["game_reward_log"])
+    assert np.array_equal(c.tables_numpy(), a.tables_numpy()) and np.array_equal(c.counters_numpy(), a.counters_numpy())
+    assert np.array_equal(c.states_numpy(), a.states_numpy()) and c.eps == a.eps and c.count == a.count
+    assert c.episode == a.episode == 9 and c.nn[1].step == a.nn[1].step
+    assert np.array_equal(c.nn[1].params.cpu().numpy(), a.nn[1].params.cpu().numpy())
+    assert np.array_equal(c.nn[1].adam_v.cpu().numpy(), a.nn[1].adam_v.cpu().numpy())

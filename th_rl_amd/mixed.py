@@ -132,6 +132,43 @@ class MixedGameBatch:
         r, a = self.shapes[agent]; o = self.offsets[agent]
         return self.counter[game, o:o + r * a].cpu().numpy().astype(np.float64).reshape(r, a)
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything a continued run needs (plain tensors / numbers: loads with weights_only=True)."""
+        return dict(version=1, kind="mixed", n_games=self.G, kinds=list(self.kinds), shapes=[list(x) for x in self.shapes],
+                    dtype=self.dtype, seed=self.seed, game_offset=self.game_offset, episode=self.episode,
+                    eps=[float(x) for x in self.eps], count=[int(x) for x in self.count],
+                    q=self.q.cpu(), counter=self.counter.cpu(), state=self.state.cpu(),
+                    buffers=[{k: v.cpu() for k, v in b.items()} for b in self.buf],
+                    nn={int(i): dict(params=rb.params.cpu(), adam_m=rb.adam_m.cpu(), adam_v=rb.adam_v.cpu(),
+                                     step=int(rb.step)) for i, rb in self.nn.items()})
+
+    def save(self, path):
+        _torch().save(self.state_dict(), path)
+
+    def load_state_dict(self, sd):
+        if sd.get("kind") != "mixed" or int(sd["n_games"]) != self.G or list(sd["kinds"]) != list(self.kinds) \
+                or [list(x) for x in sd["shapes"]] != [list(x) for x in self.shapes] or int(sd["dtype"]) != self.dtype:
+            raise ThrlError("checkpoint does not match this MixedGameBatch (games / agent kinds / shapes / dtype)")
+        self.q.copy_(sd["q"]); self.counter.copy_(sd["counter"]); self.state.copy_(sd["state"])
+        self.eps = [float(x) for x in sd["eps"]]
+        self.count = [int(x) for x in sd["count"]]
+        self.episode = int(sd["episode"])
+        self.seed, self.game_offset = int(sd["seed"]), int(sd["game_offset"])
+        for b, src in zip(self.buf, sd["buffers"]):
+            for k in b:
+                b[k].copy_(src[k])
+        for i, rb in self.nn.items():
+            src = sd["nn"][int(i)]
+            rb.params.copy_(src["params"]); rb.adam_m.copy_(src["adam_m"]); rb.adam_v.copy_(src["adam_v"])
+            rb.step = int(src["step"])
+            rb.seed, rb.game_offset = self.seed, self.game_offset
+        self.initialized = True
+        return self
+
+    def load(self, path):
+        return self.load_state_dict(_torch().load(path, weights_only=True))
+
     # ------------------------------------------------------------------ the step loop
     def _append(self, i, price, action, reward, nprice):
         cap = self.buf_len[i]

@@ -82,8 +82,6 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     else:
         # games with neural agents: fused episode kernel + batched network updates (mixed.py)
         from th_rl_amd.mixed import MixedGameBatch
-        if resume:
-            raise NotImplementedError("resume is available for all-QTable configs only")
         batch = MixedGameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
                                seed=seed, game_offset=int(training.get("game_offset", 0)))
     if resume:
@@ -140,7 +138,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     log = pandas.concat([rpd, apd], axis=1, keys=["rewards", "actions"])
     log.to_csv(os.path.join(exp_path, "log.csv"), index=None)
 
-    if all_tabular and (n_games > 1 or resume or training.get("checkpoint", False)):
+    if n_games > 1 or resume or training.get("checkpoint", False):
         batch.save(os.path.join(exp_path, "batch.pt"))
 
 
