@@ -319,3 +319,24 @@ def test_stored_reference_run_plays_the_same_greedy_game():
         assert acts.shape == (100, 2) and rews.shape == (100, 2)
         assert np.array_equal(acts, d["play%d_actions" % seed]), seed
         assert np.array_equal(rews, d["play%d_rewards" % seed]), seed
+
+
+def test_mixed_batch_greedy_play_equals_protocol_play_game():
+    """MixedGameBatch.play_greedy (all games at once) == utils.play_game through the object protocol
+    on the reference's shipped agents: same states in, same mean reward / action out."""
+    from th_rl_amd.mixed import MixedGameBatch
+    from th_rl_amd.utils import load_experiment, play_game
+    loc = os.path.join(GOLDEN, "ref_run_example_config")
+    d = np.load(os.path.join(GOLDEN, "g10_stored_run.npz"))
+    config, agents, env, _, _ = load_experiment(loc)
+    G = 3
+    mb = MixedGameBatch({"agents": config["agents"], "environment": config["environment"]}, n_games=G, dtype="float64")
+    flat = np.zeros((G, mb.stride))
+    flat[:, mb.offsets[0]:mb.offsets[0] + agents[0].table.size] = agents[0].table.ravel()
+    mb.nn[1].set_params(agents[1].flat_params())
+    mb.set_tables(flat, [0.0] * G)
+    s0 = np.array([[float(d["play%d_state0" % k]) for k in range(G)]])
+    mr, ma = mb.play_greedy(iters=1, state0=s0)
+    for k in range(G):
+        np.testing.assert_allclose(mr[0, :, k], d["play%d_rewards" % k].mean(axis=0), rtol=1e-12)
+        np.testing.assert_allclose(ma[0, :, k], d["play%d_actions" % k].mean(axis=0), rtol=1e-12)

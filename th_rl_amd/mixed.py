@@ -132,6 +132,62 @@ class MixedGameBatch:
         r, a = self.shapes[agent]; o = self.offsets[agent]
         return self.counter[game, o:o + r * a].cpu().numpy().astype(np.float64).reshape(r, a)
 
+    # ------------------------------------------------------------------ greedy evaluation
+    def play_greedy(self, iters=1, state0=None):
+        """utils.play_game (utils.py:27-47) for every game: each agent's get_action (QTable: argmax
+        on the float64-encoded state; Reinforce / ActorCritic: argmax of pi; CAC: the mean action),
+        env.step, for `iters` episodes.  Returns per-iteration mean reward and mean scaled action,
+        arrays [iters, N, G].  state0 [iters, G] = the states environment.reset() would draw
+        (default: uniform(0, a) from numpy RandomState(seed)).  Learning state is not touched."""
+        torch = _torch()
+        if not self.initialized:
+            raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
+        N, G, T = self.N, self.G, self.T
+        cfg, L = ctypes.byref(self.cfg), self.L
+        noise = self.cfg.noise_prob > 0
+        if state0 is None:
+            state0 = np.random.RandomState(self.seed % (2 ** 32)).uniform(0, self.cfg.env_a, (iters, G))
+        state0 = np.asarray(state0, np.float64).reshape(iters, G)
+        with torch.cuda.device(self.device):
+            mr = torch.zeros((iters, N, G), dtype=torch.float64, device=self.device)
+            ma = torch.zeros((iters, N, G), dtype=torch.float64, device=self.device)
+            u = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            ch = torch.zeros((N, G), dtype=torch.int8, device=self.device)
+            nu = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
+            na = torch.zeros((G,), dtype=torch.float64, device=self.device) if noise else None
+            acts = torch.zeros((N, G), dtype=torch.int32, device=self.device)
+            scaled = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            nprice = torch.zeros((G,), dtype=torch.float64, device=self.device)
+            reward = torch.zeros((N, G), dtype=torch.float64, device=self.device)
+            T_t = torch.tensor(float(T), dtype=torch.float64, device=self.device)
+            for it in range(iters):
+                price = torch.from_numpy(np.ascontiguousarray(state0[it])).to(self.device)
+                for t in range(T):
+                    if noise:     # the env draws its noise uniforms in play as well (environments.py:28)
+                        _lib.check(L.thrl_op_draws(cfg, self.seed, self.game_offset, (1 << 31) + it, t, self._p(u),
+                                                   self._p(ch), None, self._p(nu), self._p(na), self._stream()),
+                                   "thrl_op_draws")
+                    for i in range(N):
+                        lo, hi = float(self.cfg.act_lo[i]), float(self.cfg.act_hi[i])
+                        if self.kinds[i] == "QTable":
+                            _lib.check(L.thrl_op_sample_action(cfg, i, self._p(self.q), self._p(price), 0.0, None, None,
+                                                               0, self._p(acts[i]), self._stream()),
+                                       "thrl_op_sample_action")
+                            _lib.check(L.thrl_op_scale(cfg, i, self._p(acts[i]), self._p(scaled[i]), self._stream()),
+                                       "thrl_op_scale")
+                        elif self.kinds[i] == "CAC":
+                            scaled[i].copy_(self.nn[i].act(price).to(torch.float64) * (hi - lo) + lo)
+                        else:
+                            A_t = torch.tensor(float(self.nn[i].A), dtype=torch.float64, device=self.device)
+                            scaled[i].copy_(torch.div(self.nn[i].act(price).to(torch.float64), A_t) * (hi - lo) + lo)
+                    _lib.check(L.thrl_op_env_step(cfg, self._p(scaled), self._p(nu), self._p(na), self._p(nprice),
+                                                  self._p(reward), self._stream()), "thrl_op_env_step")
+                    mr[it] += torch.div(reward, T_t)
+                    ma[it] += torch.div(scaled, T_t)
+                    price = nprice.clone()
+            torch.cuda.synchronize(self.device)
+        return mr.cpu().numpy(), ma.cpu().numpy()
+
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
         """Everything a continued run needs (plain tensors / numbers: loads with weights_only=True)."""
