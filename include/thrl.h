@@ -271,10 +271,10 @@ int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int
  * network update falls inside one call.  Replay buffers are rings [buf_len][G] per agent.
  */
 typedef struct {
-    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic (3 = CAC: THRL_ERR_UNSUPPORTED, use the operators) */
+    int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic, 3 = CAC */
     const float* nn_params[THRL_MAXA];   /* device [G][P] for the neural agents              */
     double*  buf_price[THRL_MAXA];       /* device [buf_len][G] state  (trainer.py:62)       */
-    int32_t* buf_action[THRL_MAXA];
+    int32_t* buf_action[THRL_MAXA];      /* CAC agents: the float32 action's bits             */
     double*  buf_reward[THRL_MAXA];
     double*  buf_nprice[THRL_MAXA];      /* next state                                       */
     double*  buf_scratch[THRL_MAXA];     /* QTable agents: old_value snapshot (agents.py:67) */

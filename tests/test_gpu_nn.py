@@ -406,7 +406,7 @@ def test_three_agent_mix_and_unsupported_fallback():
     assert np.array_equal(a.nn[1].params.cpu().numpy(), b.nn[1].params.cpu().numpy())
     three = {"agents": [dict(r), dict(r), dict(r)], "environment": env}
     c = MixedGameBatch(three, n_games=2, dtype="float32", seed=1).init_tables()
-    with pytest.raises(ThrlError, match="more than two neural agents"):
+    with pytest.raises(ThrlError, match="more than two discrete neural agents"):
         c.run(1, fused=True)
     assert c.run(3)["kernel"] == "unfused" and c.nn[0].step == 1
 
@@ -478,10 +478,9 @@ def test_cac_many_games_sampling_and_train_vs_oracle():
 
 
 def test_qtable_vs_cac_game_and_train_one(tmp_path):
-    """A QTable-vs-CAC game runs through the operator loop (the fused kernel reports CAC as
-    unsupported and the default falls back).  With T = 1 the per-game action log is the scaled
-    action of the single step: checked against the oracle on the same Philox draws.  train_one
-    writes the reference's artefacts incl. the CAC state_dict."""
+    """A QTable-vs-CAC game (fused episode kernel).  With T = 1 the per-game action log is the
+    scaled action of the single step: checked against the oracle on the same Philox draws.
+    train_one writes the reference's artefacts incl. the CAC state_dict."""
     import json
     import torch
     from th_rl_amd import trainer
@@ -492,7 +491,7 @@ def test_qtable_vs_cac_game_and_train_one(tmp_path):
     mb = MixedGameBatch(config, n_games=G, dtype="float64", seed=31).init_tables()
     w0 = mb.nn[1].params.cpu().numpy().copy(); s0 = mb.states_numpy().copy()
     out = mb.run(8)
-    assert out["kernel"] == "unfused" and mb.nn[1].step == 1 and mb.count[1] == 2
+    assert out["kernel"] == "mixed-fused" and mb.nn[1].step == 1 and mb.count[1] == 2
     for g in range(G):
         xs = O.philox([0, 0, g, 0], [31, 0])
         a = NN.cac_sample_action(w0[g], [s0[g]], [xs[2] * 2.0 ** -32], [xs[3] * 2.0 ** -32])[0]
@@ -536,3 +535,52 @@ def test_mixed_checkpoint_resume_is_exact(tmp_path):
     assert c.episode == a.episode == 9 and c.nn[1].step == a.nn[1].step
     assert np.array_equal(c.nn[1].params.cpu().numpy(), a.nn[1].params.cpu().numpy())
     assert np.array_equal(c.nn[1].adam_v.cpu().numpy(), a.nn[1].adam_v.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype,noise", [("float64", 0.0), ("float32", 0.15)])
+def test_cac_in_fused_kernel_equals_operator_loop(dtype, noise):
+    """CAC (continuous actions, network in LDS) next to a QTable and a Reinforce agent in one game:
+    the fused kernel == the per-call operator loop, bit for bit, across several network updates."""
+    from th_rl_amd.mixed import MixedGameBatch
+    T = 16
+    cac = {"name": "CAC", "gamma": 0.97, "states": 1, "action_range": [0.15, 0.45], "min_memory": 40, "entropy": 0.02}
+    config = {"agents": [dict(cac), dict(Q_AGENT, min_memory=T), dict(R_AGENT, min_memory=3 * T)],
+              "environment": dict(ENV, max_steps=T, nplayers=3, noise_prob=noise)}
+    a = MixedGameBatch(config, n_games=5, dtype=dtype, seed=23, game_offset=2).init_tables()
+    b = MixedGameBatch(config, n_games=5, dtype=dtype, seed=23, game_offset=2).init_tables()
+    ra, rb = a.run(7, fused=True), b.run(7, fused=False)
+    assert ra["kernel"] == "mixed-fused" and rb["kernel"] == "unfused"
+    assert a.nn[0].step == b.nn[0].step == 2 and a.nn[2].step == b.nn[2].step == 2
+    assert np.array_equal(ra["game_action_log"], rb["game_action_log"])
+    assert np.array_equal(ra["game_reward_log"], rb["game_reward_log"])
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy()) and np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy()) and a.count == b.count and a.eps == b.eps
+    for i in (0, 2):
+        assert np.array_equal(a.nn[i].params.cpu().numpy(), b.nn[i].params.cpu().numpy())
+    assert np.array_equal(a.buf[0]["action"].cpu().numpy(), b.buf[0]["action"].cpu().numpy())
+
+
+def test_example_config_learning_statistics_match_the_reference():
+    """The reference's example config (QTable vs Reinforce, 20,000 epochs) trained on the device for
+    64 games at once (seconds) against the reference's own runs: fixture G11 (six seeded runs made
+    here, ~750 s each on a CPU core) plus the two runs the reference ships (G10).  Random streams
+    differ by construction, so the check is statistical: the 64-game mean of reward / action over
+    the first and the last 1,000 epochs lies within 3 standard errors of the reference's mean
+    (+ 1 % slack), per agent."""
+    import json
+    import tempfile
+    import pandas
+    from th_rl_amd import trainer
+    g10 = np.load(os.path.join(os.path.dirname(GOLDEN), "g10_stored_run.npz"))
+    g11 = np.load(os.path.join(os.path.dirname(GOLDEN), "g11_example_config_stats.npz"))
+    cfg = json.load(open(os.path.join(os.path.dirname(GOLDEN), "ref_run_example_config", "config.json")))
+    cfg["training"].update(n_games=64, seed=5, print_freq=20000)
+    d = tempfile.mkdtemp()
+    json.dump(cfg, open(os.path.join(d, "c.json"), "w"))
+    trainer.train_one(os.path.join(d, "run"), os.path.join(d, "c.json"))
+    a = pandas.read_csv(os.path.join(d, "run", "log.csv"), header=[0, 1]).to_numpy()
+    assert a.shape == (20000, 4)
+    for name, mine in (("first1000", a[:1000].mean(axis=0)), ("last1000", a[-1000:].mean(axis=0))):
+        ref = np.concatenate([g11[name], g10["shipped0_" + name][None], g10["shipped1_" + name][None]])
+        mean, se = ref.mean(axis=0), ref.std(axis=0, ddof=1) / np.sqrt(len(ref))
+        assert np.all(np.abs(mine - mean) <= 3 * se + 0.01 * np.abs(mean)), (name, mine, mean, se)

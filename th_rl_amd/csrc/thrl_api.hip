@@ -607,9 +607,8 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
     a.game_reward_log = game_reward_log; a.game_action_log = game_action_log;
     a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
     for (int i = 0; i < c->n_agents; i++) {
-        if (mx->kind[i] == 3) return fail(THRL_ERR_UNSUPPORTED, "agent %d: CAC agents run through the operator loop", i);
-        if (mx->kind[i] < 0 || mx->kind[i] > 2) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
-        if (mx->kind[i] != 0 && (!mx->nn_params[i] || c->n_actions[i] > 32))
+        if (mx->kind[i] < 0 || mx->kind[i] > 3) return fail(THRL_ERR_BAD_CONFIG, "agent %d: unknown kind %d", i, mx->kind[i]);
+        if (mx->kind[i] != 0 && (!mx->nn_params[i] || (mx->kind[i] != 3 && c->n_actions[i] > 32)))
             return fail(THRL_ERR_NULL, "agent %d: a neural agent needs nn_params and actions <= 32", i);
         a.nn_stride[i] = mx->kind[i] == 2 ? (int32_t)thrl_ac_param_count(c->n_actions[i])
                                           : (int32_t)thrl_nn_param_count(c->n_actions[i]);

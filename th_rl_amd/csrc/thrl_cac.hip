@@ -4,21 +4,16 @@
 //   [fc1.weight 256 | fc1.bias 256 | fc_mu.weight 256 | fc_mu.bias | fc_std.weight 256 | fc_std.bias |
 //    fc_v.weight 256 | fc_v.bias]
 // float32 like torch; the O(N) closed forms of the [N,N] broadcasts are evaluated in float64.
-#include <math.h>
-
-#include "thrl_policy.h"
+#include "thrl_cac.h"
 #include "thrl_kernels.h"
 
 namespace thrl {
 namespace {
 
-constexpr int kP = THRL_CAC_PARAMS;
-constexpr int oW1 = 0, oB1 = kH, oWmu = 2 * kH, oBmu = 3 * kH, oWstd = 3 * kH + 1, oBstd = 4 * kH + 1,
-              oWv = 4 * kH + 2, oBv = 5 * kH + 2;
+constexpr int kP = kCacP;
+constexpr int oW1 = kCacW1, oB1 = kCacB1, oWmu = kCacWmu, oBmu = kCacBmu, oWstd = kCacWstd, oBstd = kCacBstd,
+              oWv = kCacWv, oBv = kCacBv;
 constexpr uint32_t kStreamCacInit = 0x91u;
-
-__device__ __forceinline__ float softplus_f(float s) { return s > 20.0f ? s : log1pf(expf(s)); }   // torch threshold 20
-__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + expf(-a)); }
 
 // torch.nn.Linear default init: U(-1/sqrt(fan_in), +) for weights and biases (fan_in 1 for fc1, 256 for the heads)
 __global__ void __launch_bounds__(256) k_cac_init(int G, float* params, uint64_t seed, uint64_t game_offset, int agent) {
@@ -41,26 +36,22 @@ __global__ void __launch_bounds__(256) k_cac_act(int G, const float* __restrict_
     if (g >= G) return;
     const float* w = params + (int64_t)g * kP;
     const float x = (float)price[g];
-    float pm = 0.0f, ps = 0.0f, pv = 0.0f;
-#pragma unroll
-    for (int jj = 0; jj < 4; jj++) {
-        const int j = lane + 64 * jj;
-        const float h = fmaxf(__fmaf_rn(w[oW1 + j], x, w[oB1 + j]), 0.0f);
-        pm = __fmaf_rn(w[oWmu + j], h, pm); ps = __fmaf_rn(w[oWstd + j], h, ps); pv = __fmaf_rn(w[oWv + j], h, pv);
-    }
-    const float m = wave_all(pm, OpAdd()) + w[oBmu], s = wave_all(ps, OpAdd()) + w[oBstd];
-    const float mu = 4.0f * tanhf(m), sd = softplus_f(s);
+    float mu, sd;
+    cac_policy(w, x, lane, mu, sd);
     float a = mu;
-    if (u1) {
-        const double z = sqrt(-2.0 * log(1.0 - u1[g])) * cos(6.283185307179586 * u2[g]);
-        a = mu + sd * (float)z;
-    }
+    if (u1) a = mu + sd * box_muller_f(u1[g], u2[g]);
     if (lane == 0) {
         action_out[g] = sigmoid_f(a);
         if (mu_out) mu_out[g] = mu;
         if (std_out) std_out[g] = sd;
     }
     if (v_out) {
+        float pv = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            const int j = lane + 64 * jj;
+            pv = __fmaf_rn(w[oWv + j], fmaxf(__fmaf_rn(w[oW1 + j], x, w[oB1 + j]), 0.0f), pv);
+        }
         const float v = wave_all(pv, OpAdd()) + w[oBv];
         if (lane == 0) v_out[g] = v;
     }

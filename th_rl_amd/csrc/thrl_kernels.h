@@ -121,7 +121,7 @@ struct MixedArgs {
     int64_t stride;
     EnvParams env;
     AgentParams ag[THRL_MAXA];            // QTable parameters; for a Reinforce slot: n_actions, act_lo, act_span
-    int32_t kind[THRL_MAXA];              // 0 = QTable, 1 = Reinforce, 2 = ActorCritic (same policy head)
+    int32_t kind[THRL_MAXA];              // 0 = QTable, 1 = Reinforce, 2 = ActorCritic (same policy head), 3 = CAC
     void* q; int32_t* counter; double* state;
     const float* nn_params[THRL_MAXA];    // [G][nn_stride] per Reinforce / ActorCritic agent
     int32_t nn_stride[THRL_MAXA];
@@ -132,8 +132,9 @@ struct MixedArgs {
     double* game_reward_log; double* game_action_log;                  // [n_episodes][N][G]
     uint64_t seed, game_offset, first_episode;
     int32_t n_r; int32_t ragent[2];                                    // the (at most 2) Reinforce agents
-    int32_t lds_off[THRL_MAXA];                                        // QTable agents: element offset of the table in LDS
+    int32_t lds_off[THRL_MAXA];                                        // QTable: element offset of the table in LDS; CAC: float offset
     int32_t lds_bytes;
+    int32_t n_cac, cac_lds_byte0;                                      // CAC networks (kind 3) live in LDS after the tables
 };
 // fills n_r / ragent / lds_off / lds_bytes; returns 0 or -1 with a reason when the config does not fit
 int plan_mixed(MixedArgs& a, int q_dtype, const char** why);

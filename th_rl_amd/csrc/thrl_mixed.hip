@@ -11,7 +11,7 @@
 //   * Reinforce transitions are appended to that agent's HBM replay ring; the host launches
 //     k_nn_reinforce_train when an update is due and sizes n_episodes so none falls inside.
 // Same Philox streams and the same arithmetic as the unfused operator loop: bit-identical.
-#include "thrl_policy.h"
+#include "thrl_cac.h"
 #include "thrl_kernels.h"
 
 namespace thrl {
@@ -39,6 +39,7 @@ k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
     double* const sc_tab = reinterpret_cast<double*>(smem_mx);           // [N][64] scaled action of (agent, action)
     T* const lds = reinterpret_cast<T*>(smem_mx + (size_t)a.N * 64 * sizeof(double));
+    float* const lds_cac = reinterpret_cast<float*>(smem_mx + a.cac_lds_byte0);     // [n_cac][THRL_CAC_PARAMS]
     const int g = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, G = a.G, Tn = a.T;
     const uint64_t gid = a.game_offset + (uint64_t)g;
@@ -55,6 +56,9 @@ k_mixed_wave(const MixedArgs a) {
             const int n = p.rows * p.n_actions;
             for (int e = lane; e < n; e += 64) lds[a.lds_off[i] + e] = qg[p.table_off + e];
             sc_tab[i * 64 + lane] = scale_action(lane, p);
+        } else if (a.kind[i] == 3) {
+            const float* w = a.nn_params[i] + (int64_t)g * kCacP;
+            for (int e = lane; e < kCacP; e += 64) lds_cac[a.lds_off[i] + e] = w[e];
         } else {
             // Reinforce.scale (agents.py:153-157): action / actions * (hi - lo) + lo
             sc_tab[i * 64 + lane] = __dadd_rn(__dmul_rn(__ddiv_rn((double)lane, (double)p.n_actions), p.act_span), p.act_lo);
@@ -81,11 +85,16 @@ k_mixed_wave(const MixedArgs a) {
         const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
         double acc = 0.0;                          // lane i: reward log of agent i ; lane 32+i: action log
         u32x4 xs = {0, 0, 0, 0}, xn = {0, 0, 0, 0};
+        float z_even = 0.0f, z_odd = 0.0f;         // CAC: standard normals of this lane's (step, pair)
         for (int t = 0; t < Tn; t++) {
             const int tl = t & 15;
             if (tl == 0) {                         // draws for steps t .. t+15 of every agent pair
                 xs = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), (uint32_t)(lane >> 4));
                 if (noisy) xn = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), kStreamNoise);
+                if (a.n_cac > 0) {
+                    z_even = box_muller_f(u01_32(xs.x), u01_32(xs.y));
+                    z_odd = box_muller_f(u01_32(xs.z), u01_32(xs.w));
+                }
             }
             int act_l = 0;                         // lane i: action of agent i
             double scaled_l = 0.0;                 // lanes i and 32+i: scaled action of agent i
@@ -120,6 +129,18 @@ k_mixed_wave(const MixedArgs a) {
                 aa = rfl(aa);
                 const double sc = sc_tab[i * 64 + aa];
                 if (my_agent == i) { act_l = aa; scaled_l = sc; }
+            }
+            // ---- CAC.sample_action (agents.py:377-381): the action is a float in (0,1), kept as its bits
+            if (a.n_cac > 0) {
+                for (int i = 0; i < N; i++) {
+                    if (a.kind[i] != 3) continue;
+                    float mu, sd;
+                    cac_policy(lds_cac + a.lds_off[i], (float)price, lane, mu, sd);
+                    const float z = lane_val((i & 1) ? z_odd : z_even, (i >> 1) * 16 + tl);
+                    const float action = sigmoid_f(mu + sd * z);
+                    const double sc = __dadd_rn(__dmul_rn((double)action, a.ag[i].act_span), a.ag[i].act_lo);   // CAC.scale
+                    if (my_agent == i) { act_l = __float_as_int(action); scaled_l = sc; }
+                }
             }
             // ---- NoisyPriceState.step (environments.py:25-39)
             double a_eff = a.env.a;
@@ -250,8 +271,9 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
     int off = 0;
     for (int i = 0; i < a.N; i++) {
         a.lds_off[i] = 0;
+        if (a.kind[i] == 3) continue;                       // CAC: weights in LDS, placed below
         if (a.kind[i] != 0) {
-            if (a.n_r == 2) { *why = "more than two neural agents"; return -1; }
+            if (a.n_r == 2) { *why = "more than two discrete neural agents"; return -1; }
             if (a.ag[i].n_actions > kMaxA) { *why = "neural agent with more than 32 actions"; return -1; }
             a.ragent[a.n_r++] = i;
         } else {
@@ -260,8 +282,14 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
             off += (a.ag[i].rows * a.ag[i].n_actions + 3) & ~3;
         }
     }
-    a.lds_bytes = a.N * 64 * 8 + off * esz;            // scale tables, then the Q-tables
-    if (a.lds_bytes > 64 * 1024) { *why = "QTable tables of one game exceed 64 KiB of LDS"; return -1; }
+    a.lds_bytes = a.N * 64 * 8 + off * esz;            // scale tables, then the Q-tables, then CAC networks
+    a.lds_bytes = (a.lds_bytes + 15) & ~15;
+    a.cac_lds_byte0 = a.lds_bytes;
+    a.n_cac = 0;
+    for (int i = 0; i < a.N; i++)
+        if (a.kind[i] == 3) { a.lds_off[i] = a.n_cac * ((kCacP + 3) & ~3); a.n_cac++; }
+    a.lds_bytes += a.n_cac * ((kCacP + 3) & ~3) * 4;
+    if (a.lds_bytes > 64 * 1024) { *why = "tables and CAC networks of one game exceed 64 KiB of LDS"; return -1; }
     return 0;
 }
 

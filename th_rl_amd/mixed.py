@@ -254,7 +254,7 @@ class MixedGameBatch:
         """n_episodes for all games.  fused=True: thrl_mixed_episodes, one launch per run of episodes
         between network updates; fused=False: the per-call operator loop (same results); None
         (default): fused unless the library reports the configuration as unsupported by that kernel
-        (more than two neural agents, Q-tables beyond 64 KiB of LDS per game, > 64 actions)."""
+        (more than two Reinforce / ActorCritic agents, tables beyond 64 KiB of LDS per game, > 64 actions)."""
         if fused is None:
             try:
                 return self._run_fused(int(n_episodes))
