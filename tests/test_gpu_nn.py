@@ -194,7 +194,6 @@ def test_qtable_vs_reinforce_game_against_composed_oracle():
         for e in range(E):
             rl = np.zeros(2); al = np.zeros(2)
             for t in range(T):
-                x = O.philox([t, e, 11 + g - 11 + g * 0 + (g), 0], [11, 0]) if False else None
                 ctr = [t, e, g, 0]
                 xs = O.philox(ctr, [11, 0])
                 u0 = xs[0] * 2.0 ** -32; c0 = (xs[1] * 21) >> 32; u1 = xs[2] * 2.0 ** -32
