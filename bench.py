@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--games", type=int, default=1 << 20, help="games per GPU")
-    ap.add_argument("--chunk", type=int, default=10, help="episodes per kernel launch (<=16)")
+    ap.add_argument("--chunk", type=int, default=25, help="episodes per kernel launch (<=32)")
     ap.add_argument("--nn-loop", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--nn-agents", default="rr", choices=["rr", "qr", "qq"])
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
@@ -146,7 +146,7 @@ def main():
     torch.cuda.set_device(dev)
 
     G = args.games
-    chunk = max(1, min(16, args.chunk))
+    chunk = max(1, min(32, args.chunk))
     if args.noise_prob is not None:
         CFG["environment"]["noise_prob"] = float(args.noise_prob)
     gb = GameBatch(CFG, n_games=G, device=dev, dtype="float32", kernel=args.kernel, seed=0,

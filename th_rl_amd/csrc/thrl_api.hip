@@ -202,7 +202,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
 constexpr size_t kMaxWaves = 256 * 32;          // at most 32 resident waves on each of 256 CUs
-constexpr size_t kTlogBytesPerWave = (size_t)kWaveMaxEpisodes * 4 * 64 * 4;   // 16 episodes x 4 segments x 64 steps
+constexpr size_t kTlogBytesPerWave = (size_t)kWaveMaxEpisodes * 4 * 64 * 4;   // 32 episodes x 4 segments x 64 steps
+constexpr size_t kPartialBytes = kMaxWaves * 4 * kWaveMaxEpisodes * sizeof(double);
 
 }  // namespace
 
@@ -230,7 +231,7 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
 }
 size_t thrl_workspace_bytes(const thrl_cfg* c) {
     (void)c;
-    return kLutRegion + kMaxWaves * 64 * sizeof(double) + kMaxWaves * kTlogBytesPerWave;
+    return kLutRegion + kPartialBytes + kMaxWaves * kTlogBytesPerWave;
 }
 int thrl_select_kernel(const thrl_cfg* c, int injected) {
     if (validate(c) != THRL_OK) return THRL_ERR_BAD_CONFIG;
@@ -336,7 +337,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut_ns = lut;
     a.partial = (double*)((char*)b->workspace + kLutRegion);
-    a.tlog = (uint32_t*)((char*)b->workspace + kLutRegion + kMaxWaves * 64 * sizeof(double));
+    a.tlog = (uint32_t*)((char*)b->workspace + kLutRegion + kPartialBytes);
     a.seed = run->seed; a.game_offset = run->game_offset;
     a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
     a.sw_eps_step = b->sweep_eps_step; a.sw_eps = b->sweep_eps; a.sw_noise_prob = b->sweep_noise_prob;

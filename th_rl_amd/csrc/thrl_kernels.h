@@ -38,7 +38,7 @@ struct GenericArgs {
 };
 
 // ---- fused wave-per-game kernel (thrl_wave.hip) -----------------------------
-constexpr int kWaveMaxEpisodes = 16;   // 16 episodes x 4 log values = the 64 lanes of the accumulator
+constexpr int kWaveMaxEpisodes = 32;   // 32 episodes x 4 log values = the 64 lanes of two accumulators
 
 struct WaveArgs {
     int32_t G, T, A, rows;          // homogeneous 2-agent game
@@ -55,7 +55,7 @@ struct WaveArgs {
     int32_t* counter;
     double* state;
     const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
-    double* partial;                // device [total_waves][E][4] per-wave log sums
+    double* partial;                // device [total_waves][kWaveMaxEpisodes][4] per-wave log sums
     uint32_t* tlog;                 // device [total_waves][16 episodes][NSEG][64] packed transitions
     const double* inj_u;            // parity mode: device [n_episodes][T][2][G] uniforms, or null (Philox)
     const int8_t* inj_choice;       // parity mode: device [n_episodes][T][2][G] random.choice indices

@@ -212,7 +212,7 @@ k_wave_episodes(const WaveArgs a) {
     const AgentParams& p1 = a.ag[1];
     const double inv_T_den = (double)T;
 
-    double acc = 0.0;   // lane (e*4+k): sum over this wave's games of episode-e log value k
+    double acc = 0.0, acc_hi = 0.0;   // lane ((e&15)*4+k): sum over this wave's games of episode-e log value k (e < 16 / e >= 16)
     const int wave_gid = blockIdx.x * a.waves_per_block + wib;
 
     for (int g = wave_gid; g < a.G; g += a.total_waves) {
@@ -538,7 +538,7 @@ k_wave_episodes(const WaveArgs a) {
             {
                 double v = wave_sum4(lr0, lr1, la0, la1, lane);
                 if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
-                if ((lane >> 2) == e) acc += v;
+                if ((lane >> 2) == (e & 15)) { if (e < 16) acc += v; else acc_hi += v; }
             }
             // epsilon decays after every train_net call (agents.py:78)
             if (SWEEP) {
@@ -568,7 +568,7 @@ k_wave_episodes(const WaveArgs a) {
 
         // ---- visit counters of this game (agents.py:76).  The tables are back in HBM, so
         //      the wave's LDS region is free: build the launch's visit histogram there
-        //      (u16 pairs in dwords, ds_add_u32; E*T <= 16*256 < 65536 so no carry) from the
+        //      (u16 pairs in dwords, ds_add_u32; E*T <= 32*256 < 65536 so no carry) from the
         //      transition log, then apply it to the counter window with plain coalesced
         //      read-add-write -- this game's counters belong to this wave alone, so no
         //      global atomics are needed (2e9 scattered atomics per launch were a 70 ms floor).
@@ -633,7 +633,8 @@ k_wave_episodes(const WaveArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     }
-    a.partial[(size_t)wave_gid * 64 + lane] = acc;
+    a.partial[(size_t)wave_gid * 128 + lane] = acc;
+    a.partial[(size_t)wave_gid * 128 + 64 + lane] = acc_hi;
 }
 
 // fixed-order reduction of the per-wave partials -> mean logs [E][2].
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int 
     const int e = j >> 2, k = j & 3;
     if (e >= n_episodes) return;
     double s = 0.0;
-    for (int w = threadIdx.x; w < total_waves; w += 256) s += partial[(size_t)w * 64 + j];
+    for (int w = threadIdx.x; w < total_waves; w += 256) s += partial[(size_t)w * 128 + j];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -703,7 +704,7 @@ int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t 
 
 int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,
                        double* action_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_wave_reduce, dim3(64), dim3(256), 0, s, partial, total_waves, n_episodes, (double)G,
+    hipLaunchKernelGGL(k_wave_reduce, dim3(4 * kWaveMaxEpisodes), dim3(256), 0, s, partial, total_waves, n_episodes, (double)G,
                        reward_log, action_log);
     return (int)hipGetLastError();
 }
