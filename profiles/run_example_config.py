@@ -1,6 +1,6 @@
 import json, os, sys, time, tempfile
 import numpy as np, pandas
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from th_rl_amd import trainer
 cfg = {"agents": [{"name": "QTable", "gamma": 0.95, "actions": 21, "states": 100, "alpha": 0.1, "eps_end": 0.001,
                    "epsilon": 0.5, "eps_step": 0.9995, "action_range": [0.2, 0.4]},

@@ -2,7 +2,7 @@
 """Turn raw rocprofv3 output (gpurun_out/<tag>_stats, <tag>_pmc_*) into the small
 summaries committed under profiles/ and into profiles/traffic.json (read by bench.py).
 
-    python profiles/summarize.py r01 --games 1048576 --episodes-per-launch 10
+    python profiles/summarize.py r01 --games 1048576 --episodes-per-launch 25
 
 HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are collected in
 SEPARATE --pmc passes, are in KiB, and FETCH_SIZE under-reports wide coalesced reads by
@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("--games", type=int, default=1 << 20)
-    ap.add_argument("--episodes-per-launch", type=int, default=10)
+    ap.add_argument("--episodes-per-launch", type=int, default=25)
     ap.add_argument("--kernel", default="k_wave_episodes")
     args = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out")

@@ -27,14 +27,26 @@ def up_to_date():
 
 
 def build(force=False, verbose=False):
+    """Each source is compiled to an object in parallel (one hipcc per source), then linked."""
     if not force and up_to_date():
         return LIB
+    import concurrent.futures
+    import tempfile
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    cflags = [f for f in FLAGS if f != "-shared"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        cflags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    with tempfile.TemporaryDirectory() as tmp:
+        def compile_one(src):
+            obj = os.path.join(tmp, src.replace(".hip", ".o"))
+            cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+            objs = list(ex.map(compile_one, SOURCES))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB], cwd=CSRC)
     return LIB
 
 

@@ -33,7 +33,7 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 // scaled action / reward) and is picked with v_readlane, so the large bodies -- the policy, the
 // TD update -- exist once in the code, not once per agent slot.
 // Draw layout: one Philox batch covers 16 steps x 4 agent pairs, lane = pair * 16 + (step & 15).
-template <typename T, int NR, int APAD, int NA>
+template <typename T, int NR, int APAD, int NA, bool CAC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : (NR == 0 ? 4 : 1))))
 k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
@@ -56,7 +56,7 @@ k_mixed_wave(const MixedArgs a) {
             const int n = p.rows * p.n_actions;
             for (int e = lane; e < n; e += 64) lds[a.lds_off[i] + e] = qg[p.table_off + e];
             sc_tab[i * 64 + lane] = scale_action(lane, p);
-        } else if (a.kind[i] == 3) {
+        } else if (CAC && a.kind[i] == 3) {
             const float* w = a.nn_params[i] + (int64_t)g * kCacP;
             for (int e = lane; e < kCacP; e += 64) lds_cac[a.lds_off[i] + e] = w[e];
         } else {
@@ -91,7 +91,7 @@ k_mixed_wave(const MixedArgs a) {
             if (tl == 0) {                         // draws for steps t .. t+15 of every agent pair
                 xs = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), (uint32_t)(lane >> 4));
                 if (noisy) xn = draw(a.seed, gid, eg, (uint32_t)(t + (lane & 15)), kStreamNoise);
-                if (a.n_cac > 0) {
+                if (CAC) {
                     z_even = box_muller_f(u01_32(xs.x), u01_32(xs.y));
                     z_odd = box_muller_f(u01_32(xs.z), u01_32(xs.w));
                 }
@@ -131,7 +131,7 @@ k_mixed_wave(const MixedArgs a) {
                 if (my_agent == i) { act_l = aa; scaled_l = sc; }
             }
             // ---- CAC.sample_action (agents.py:377-381): the action is a float in (0,1), kept as its bits
-            if (a.n_cac > 0) {
+            if (CAC) {
                 for (int i = 0; i < N; i++) {
                     if (a.kind[i] != 3) continue;
                     float mu, sd;
@@ -238,9 +238,9 @@ k_mixed_wave(const MixedArgs a) {
     if (lane == 0) a.state[g] = price;
 }
 
-template <typename T, int NR, int APAD, int NA>
-int launch_one(const MixedArgs& a, hipStream_t s) {
-    auto kern = k_mixed_wave<T, NR, APAD, NA>;
+template <typename T, int NR, int APAD, int NA, bool CAC>
+int launch_cac(const MixedArgs& a, hipStream_t s) {
+    auto kern = k_mixed_wave<T, NR, APAD, NA, CAC>;
     if (a.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            a.lds_bytes);
@@ -248,6 +248,12 @@ int launch_one(const MixedArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL(kern, dim3(a.G), dim3(64), (size_t)a.lds_bytes, s, a);
     return (int)hipGetLastError();
+}
+
+// the CAC code (Box-Muller, LDS-resident heads) is compiled only into the variants that need it
+template <typename T, int NR, int APAD, int NA>
+int launch_one(const MixedArgs& a, hipStream_t s) {
+    return a.n_cac > 0 ? launch_cac<T, NR, APAD, NA, true>(a, s) : launch_cac<T, NR, APAD, NA, false>(a, s);
 }
 
 template <typename T, int NA>
