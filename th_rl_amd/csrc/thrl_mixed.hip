@@ -34,7 +34,7 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 // TD update -- exist once in the code, not once per agent slot.
 // Draw layout: one Philox batch covers 16 steps x 4 agent pairs, lane = pair * 16 + (step & 15).
 template <typename T, int NR, int APAD, int NA, bool CAC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : (NR == 0 ? 4 : 1))))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : (NR == 0 ? 4 : 2))))
 k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
     double* const sc_tab = reinterpret_cast<double*>(smem_mx);           // [N][64] scaled action of (agent, action)
