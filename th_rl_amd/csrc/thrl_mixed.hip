@@ -17,6 +17,8 @@
 namespace thrl {
 namespace {
 
+constexpr int kMemo = 64;          // memoised policy CDFs per network (one lane of the tag register each)
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ double lane_f64(double v, int l) {
@@ -33,13 +35,19 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 // scaled action / reward) and is picked with v_readlane, so the large bodies -- the policy, the
 // TD update -- exist once in the code, not once per agent slot.
 // Draw layout: one Philox batch covers 16 steps x 4 agent pairs, lane = pair * 16 + (step & 15).
-template <typename T, int NR, int APAD, int NA, bool CAC>
+template <typename T, int NR, int APAD, int NA, bool CAC, bool MEMO>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : (NR == 0 ? 4 : 2))))
 k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
     double* const sc_tab = reinterpret_cast<double*>(smem_mx);           // [N][64] scaled action of (agent, action)
     T* const lds = reinterpret_cast<T*>(smem_mx + (size_t)a.N * 64 * sizeof(double));
     float* const lds_cac = reinterpret_cast<float*>(smem_mx + a.cac_lds_byte0);     // [n_cac][THRL_CAC_PARAMS]
+    // Policy memo: the networks do not change inside a launch and the price lives on a small grid
+    // (noise-free games: one value per pair of actions), so the CDF the policy returns for a state
+    // is kept -- kMemo entries per network, tag = the float32 state's bits, lane e of `tag` = entry e.
+    float* const lds_memo = reinterpret_cast<float*>(smem_mx + a.memo_lds_byte0);   // [NR][kMemo][APAD]
+    unsigned tag0 = 0u, tag1 = 0u;
+    int nmemo0 = 0, nmemo1 = 0;
     const int g = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, G = a.G, Tn = a.T;
     const uint64_t gid = a.game_offset + (uint64_t)g;
@@ -125,7 +133,26 @@ k_mixed_wave(const MixedArgs a) {
                 const int dl = (i >> 1) * 16 + tl;
                 const uint32_t xu = lane_u32((i & 1) ? xs.z : xs.x, dl);
                 const int A = a.ag[i].n_actions;
-                int aa = policy_act(r == 0 ? net0 : net1, A, (float)price, true, (float)u01_32(xu), lane, (float*)nullptr);
+                const float x = (float)price;
+                const unsigned key = __float_as_uint(x);
+                unsigned& tag = r == 0 ? tag0 : tag1;
+                int& nmemo = r == 0 ? nmemo0 : nmemo1;
+                float* memo = lds_memo + r * kMemo * APAD;
+                const unsigned long long found = MEMO ? __ballot(tag == key && lane < min(nmemo, kMemo)) : 0ull;
+                float c;
+                if (MEMO && found) {
+                    c = memo[(int)__builtin_ctzll(found) * APAD + min(lane >> 1, APAD - 1)];
+                } else {
+                    c = policy_cdf(policy_probs(r == 0 ? net0 : net1, A, x, lane));
+                    if (MEMO) {
+                        const int slot = nmemo & (kMemo - 1);                // round-robin replacement
+                        if (!(lane & 1) && (lane >> 1) < APAD) memo[slot * APAD + (lane >> 1)] = c;
+                        if (lane == slot) tag = key;
+                        nmemo += 1;
+                        if (nmemo >= 2 * kMemo) nmemo -= kMemo;
+                    }
+                }
+                int aa = policy_pick(c, (float)u01_32(xu), A, lane);
                 aa = rfl(aa);
                 const double sc = sc_tab[i * 64 + aa];
                 if (my_agent == i) { act_l = aa; scaled_l = sc; }
@@ -238,9 +265,9 @@ k_mixed_wave(const MixedArgs a) {
     if (lane == 0) a.state[g] = price;
 }
 
-template <typename T, int NR, int APAD, int NA, bool CAC>
+template <typename T, int NR, int APAD, int NA, bool CAC, bool MEMO>
 int launch_cac(const MixedArgs& a, hipStream_t s) {
-    auto kern = k_mixed_wave<T, NR, APAD, NA, CAC>;
+    auto kern = k_mixed_wave<T, NR, APAD, NA, CAC, MEMO>;
     if (a.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            a.lds_bytes);
@@ -253,7 +280,9 @@ int launch_cac(const MixedArgs& a, hipStream_t s) {
 // the CAC code (Box-Muller, LDS-resident heads) is compiled only into the variants that need it
 template <typename T, int NR, int APAD, int NA>
 int launch_one(const MixedArgs& a, hipStream_t s) {
-    return a.n_cac > 0 ? launch_cac<T, NR, APAD, NA, true>(a, s) : launch_cac<T, NR, APAD, NA, false>(a, s);
+    if (a.n_cac > 0) return launch_cac<T, NR, APAD, NA, true, false>(a, s);
+    if (NR > 0 && a.memo_on) return launch_cac<T, NR, APAD, NA, false, true>(a, s);
+    return launch_cac<T, NR, APAD, NA, false, false>(a, s);
 }
 
 template <typename T, int NA>
@@ -295,6 +324,40 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
     for (int i = 0; i < a.N; i++)
         if (a.kind[i] == 3) { a.lds_off[i] = a.n_cac * ((kCacP + 3) & ~3); a.n_cac++; }
     a.lds_bytes += a.n_cac * ((kCacP + 3) & ~3) * 4;
+    // Policy memo only where it can pay: every agent discrete, little env noise, and at most kMemo
+    // distinct float32 prices over the whole action product (2 agents on the same grid: 41).
+    a.memo_lds_byte0 = a.lds_bytes;
+    a.memo_on = 0;
+    if (a.n_r > 0 && a.n_cac == 0 && a.env.noise_prob <= 0.1) {
+        long combos = 1;
+        for (int i = 0; i < a.N && combos <= 4096; i++) combos *= a.ag[i].n_actions;
+        if (combos <= 4096) {
+            float seen[kMemo + 1];
+            int n_seen = 0;
+            int k[THRL_MAXA] = {0};
+            for (long c = 0; c < combos && n_seen <= kMemo; c++) {
+                double Q = 0.0;
+                for (int i = 0; i < a.N; i++) {
+                    const AgentParams& p = a.ag[i];
+                    const double den = a.kind[i] == 0 ? p.act_den : (double)p.n_actions;   // QTable / Reinforce scale
+                    Q = Q + a.env.ratio * ((double)k[i] / den * p.act_span + p.act_lo);
+                }
+                double pr = a.env.a - a.env.b * Q;
+                if (!(pr > 0.0)) pr = 0.0;
+                const float x = (float)pr;
+                int j = 0;
+                while (j < n_seen && seen[j] != x) j++;
+                if (j == n_seen) seen[n_seen++] = x;
+                for (int i = 0; i < a.N; i++) { if (++k[i] < a.ag[i].n_actions) break; k[i] = 0; }
+            }
+            a.memo_on = n_seen <= kMemo;
+        }
+    }
+    if (a.memo_on) {
+        int amax = 0;
+        for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
+        a.lds_bytes += a.n_r * kMemo * (amax <= 24 ? 24 : 32) * 4;
+    }
     if (a.lds_bytes > 64 * 1024) { *why = "tables and CAC networks of one game exceed 64 KiB of LDS"; return -1; }
     return 0;
 }

@@ -131,11 +131,10 @@ __device__ __forceinline__ void policy_load(PolicyRegs<APAD>& r, const float* __
     r.b2 = (lane >> 1) < A ? w[2 * kH + A * kH + (lane >> 1)] : 0.0f;
 }
 
-// Returns the action to every lane (wave-uniform).  sample: inverse CDF on `uu`; else argmax
-// (get_action, agents.py:165-168).  Lane 2k holds action k's probability in *prob (odd lanes 0).
+// Action probabilities of the policy for the float32 state x: lane 2k holds p_k (odd lanes and
+// k >= A hold 0).
 template <int APAD>
-__device__ __forceinline__ int policy_act(const PolicyRegs<APAD>& r, int A, float x, bool sample, float uu, int lane,
-                                          float* prob) {
+__device__ __forceinline__ float policy_probs(const PolicyRegs<APAD>& r, int A, float x, int lane) {
     float h[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) h[j] = fmaxf(__fmaf_rn(r.w1[j], x, r.b1[j]), 0.0f);
@@ -155,23 +154,37 @@ __device__ __forceinline__ int policy_act(const PolicyRegs<APAD>& r, int A, floa
     const float m = wave_all(valid ? z : -INFINITY, OpMax());
     const float e = mine ? expf(z - m) : 0.0f;
     const float sum = wave_all(e, OpAdd());
-    const float p = e / sum;
+    return e / sum;
+}
+// inclusive scan of the probabilities in lane order: lane 2k (and 2k+1) holds p_0 + ... + p_k
+__device__ __forceinline__ float policy_cdf(float p) {
+    float c = p;
+    c = c + dpp_f0<0x111, 0xF>(c);                         // row_shr:1
+    c = c + dpp_f0<0x112, 0xF>(c);
+    c = c + dpp_f0<0x114, 0xF>(c);
+    c = c + dpp_f0<0x118, 0xF>(c);
+    c = c + dpp_f0<0x142, 0xA>(c);                         // row_bcast:15 into rows 1 and 3
+    c = c + dpp_f0<0x143, 0xC>(c);                         // row_bcast:31 into rows 2 and 3
+    return c;
+}
+// Categorical sample by inverse CDF: the first action whose cumulative probability exceeds uu
+__device__ __forceinline__ int policy_pick(float c, float uu, int A, int lane) {
+    const bool mine = (lane >> 1) < A && !(lane & 1);
+    const unsigned long long hit = __ballot(mine && uu < c);
+    return hit ? (int)(__builtin_ctzll(hit) >> 1) : A - 1;
+}
+
+// Returns the action to every lane (wave-uniform).  sample: inverse CDF on `uu`; else argmax
+// (get_action, agents.py:165-168).  Lane 2k holds action k's probability in *prob (odd lanes 0).
+template <int APAD>
+__device__ __forceinline__ int policy_act(const PolicyRegs<APAD>& r, int A, float x, bool sample, float uu, int lane,
+                                          float* prob) {
+    const float p = policy_probs(r, A, x, lane);
     if (prob) *prob = p;
-    unsigned long long hit;
-    if (sample) {
-        float c = p;                                           // inclusive scan in lane order
-        c = c + dpp_f0<0x111, 0xF>(c);                         // row_shr:1
-        c = c + dpp_f0<0x112, 0xF>(c);
-        c = c + dpp_f0<0x114, 0xF>(c);
-        c = c + dpp_f0<0x118, 0xF>(c);
-        c = c + dpp_f0<0x142, 0xA>(c);                         // row_bcast:15 into rows 1 and 3
-        c = c + dpp_f0<0x143, 0xC>(c);                         // row_bcast:31 into rows 2 and 3
-        hit = __ballot(mine && uu < c);
-        return hit ? (int)(__builtin_ctzll(hit) >> 1) : A - 1;
-    }
+    if (sample) return policy_pick(policy_cdf(p), uu, A, lane);
+    const bool mine = (lane >> 1) < A && !(lane & 1);
     const float pm = wave_all(p, OpMax());
-    hit = __ballot(mine && p == pm);
-    return (int)(__builtin_ctzll(hit) >> 1);
+    return (int)(__builtin_ctzll(__ballot(mine && p == pm)) >> 1);
 }
 
 }  // namespace thrl
