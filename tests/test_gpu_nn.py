@@ -583,3 +583,27 @@ def test_example_config_learning_statistics_match_the_reference():
         ref = np.concatenate([g11[name], g10["shipped0_" + name][None], g10["shipped1_" + name][None]])
         mean, se = ref.mean(axis=0), ref.std(axis=0, ddof=1) / np.sqrt(len(ref))
         assert np.all(np.abs(mine - mean) <= 3 * se + 0.01 * np.abs(mean)), (name, mine, mean, se)
+
+
+@pytest.mark.parametrize("distinct", [3, 64, 65, 500])
+def test_reinforce_update_state_dedupe_and_plain_path(distinct):
+    """The update folds transitions that share a state (<= 64 distinct states per batch) and takes the
+    plain per-transition path beyond that; both against the numpy oracle, and deterministic."""
+    G, n = 6, 500
+    rs = np.random.RandomState(distinct)
+    grid = np.sort(rs.uniform(2.0, 6.0, distinct))
+    price = grid[rs.randint(0, distinct, (n, G))]
+    price[:distinct, :] = grid[:, None]                      # every state occurs
+    action = rs.randint(0, 21, (n, G))
+    reward = rs.uniform(5, 15, (n, G))
+    outs = []
+    for rep in range(2):
+        rb = _rb(G, gamma=0.97, entropy=0.01, seed=3).init()
+        w0 = rb.params.cpu().numpy().copy()
+        g = rb.train(price, action, reward, want_grad=True).cpu().numpy()
+        outs.append((g, rb.params.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for k in (0, 5):
+        ow, om, ov, os_, og = NN.train_net(w0[k], np.zeros(rb.P, np.float32), np.zeros(rb.P, np.float32), 0, 21,
+                                           price[:, k], action[:, k], reward[:, k], 0.97, 0.01)
+        np.testing.assert_allclose(outs[0][0][k], og, rtol=2e-4, atol=2e-6)

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
 //            halves are added through LDS after the last chunk.
 // Rows of fc_pi^T and of dz are padded to kPad = 24 or 32 floats (zero) for aligned vector LDS reads.
 constexpr int kChunk = 256;
+constexpr int kUmax = 64;          // state dedupe: at most this many distinct states per update
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -92,6 +93,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     float* xps = red + 8;                                   // [NX]  next states           (AC only)
     float* gvs = xps + (AC ? NX : 0);                       // [NX]  c_i, then d loss/d v_i (AC only)
     float* wvs = gvs + (AC ? NX : 0);                       // [kH]  fc_v.weight            (AC only)
+    // Reinforce only: state dedupe (see below)
+    int* uid = reinterpret_cast<int*>(red + 8);             // [NX]  index of the transition's distinct state
+    float* xu = reinterpret_cast<float*>(uid + NX);         // [kChunk] the distinct states, zero padded
+    int* ucnt = reinterpret_cast<int*>(xu + kChunk);        // [kUmax] transitions per distinct state
+    int* redi = ucnt + kUmax;                               // [8]
+    long long* sga = reinterpret_cast<long long*>(redi + 8);   // [kUmax][kPad] sum of returns by (state, action), 2^-40 fixed point
     const int g = blockIdx.x, tid = threadIdx.x;
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
@@ -109,6 +116,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     if (AC) wvs[tid] = w[Pp + tid];
     __syncthreads();
     float wva = 0.0f, wvb = 0.0f, gbv = 0.0f;
+    int U = 0;                                              // > 0: passes run over U distinct states
     if (!AC) {
         // discounted return: the reference's serial recurrence, last to first (agents.py:178-181)
         if (tid == 0)
@@ -121,6 +129,75 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         for (int n = tid; n < N; n += 256) { const float d = Gs[n] - mean; part += d * d; }
         const float sd = sqrtf(block_sum(part, red) / (float)(N - 1));      // torch.std: unbiased
         for (int n = tid; n < N; n += 256) Gs[n] = (Gs[n] - mean) / sd;
+        __syncthreads();
+        // ---- State dedupe.  In a noise-free game the price takes one value per pair of actions, so
+        // the n transitions visit few DISTINCT states (two agents on the same grid: 41).  The forward
+        // pass depends on the state only, and every gradient is linear in d loss/d logits, so the
+        // transitions of a state are folded first:
+        //   sum_{n in u} dz_n[k] = (p_u[k]*SG_u - SGA_u[k] + cnt_u*ent*p_u[k]*(log p_u[k] + H_u)) / N
+        // with SG_u = sum of returns, SGA_u[k] = sum of returns of the transitions that took action k.
+        // Passes A and B then run over the U distinct states instead of the n transitions.  The sums
+        // are accumulated in 2^-40 fixed point with integer LDS atomics: order independent, so the
+        // update stays deterministic.  More than kUmax distinct states: the plain path.
+        {
+            constexpr int kOwn = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
+            float xq[kOwn];
+            unsigned open_mask = 0u;
+#pragma unroll
+            for (int q2 = 0; q2 < kOwn; q2++) {
+                const int n = tid + 256 * q2;
+                xq[q2] = n < N ? xs[n] : 0.0f;
+                if (n < N) open_mask |= 1u << q2;
+            }
+            xu[tid] = 0.0f;
+            if (tid < kUmax) ucnt[tid] = 0;
+            for (int k = tid; k < kUmax * kPad; k += 256) sga[k] = 0;
+            int round = 0;
+            bool hopeless = false;
+            for (; round < kUmax; round++) {
+                if (round == 8) {        // 8 states cover less than an eighth of the batch: too many states, stop
+                    int open_n = __popc(open_mask);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) open_n += __shfl_xor(open_n, o, 64);
+                    __syncthreads();
+                    if ((tid & 63) == 0) redi[4 + (tid >> 6)] = open_n;
+                    __syncthreads();
+                    if (redi[4] + redi[5] + redi[6] + redi[7] > N - N / 8) { hopeless = true; break; }
+                }
+                int cand = open_mask ? tid + 256 * (__ffs((int)open_mask) - 1) : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+                __syncthreads();
+                if ((tid & 63) == 0) redi[tid >> 6] = cand;
+                __syncthreads();
+                const int first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+                if (first == 0x7fffffff) break;                       // every transition has its state
+                const float xr = xs[first];
+                if (tid == 0) xu[round] = xr;
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++)
+                    if (((open_mask >> q2) & 1u) && xq[q2] == xr) { uid[tid + 256 * q2] = round; open_mask &= ~(1u << q2); }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) redi[4 + (tid >> 6)] = 0;
+            __syncthreads();
+            if (open_mask) redi[4 + (tid >> 6)] = 1;
+            __syncthreads();
+            const bool leftover = (redi[4] | redi[5] | redi[6] | redi[7]) != 0;
+            U = (leftover || hopeless) ? 0 : round;
+            if (U > 0) {
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++) {
+                    const int n = tid + 256 * q2;
+                    if (n < N) {
+                        const int u = uid[n];
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[(size_t)n * G + g]]),
+                                  (unsigned long long)llrint((double)Gs[n] * 1099511627776.0));
+                        atomicAdd(&ucnt[u], 1);
+                    }
+                }
+            }
+        }
     } else {
         // v(s), v(s') per transition (agents.py:287-288), c_i = gamma*v'_i - v_i
         const float bv = w[Pp + kH];
@@ -165,10 +242,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     constexpr int kGp = kPad / 8;                           // action pairs per thread
     const int q = tid >> 2, kg = tid & 3;
 
-    for (int c0 = 0; c0 < N; c0 += kChunk) {
-        const int cn = min(kChunk, N - c0);
+    const float* xa = U > 0 ? xu : xs;                      // the states the passes run over
+    const int NN = U > 0 ? U : N;
+    for (int c0 = 0; c0 < NN; c0 += kChunk) {
+        const int cn = min(kChunk, NN - c0);
         {   // ---- pass A1: logits (without bias) into dz
-            const f4 x4 = *reinterpret_cast<const f4*>(xs + c0 + 4 * q);
+            const f4 x4 = *reinterpret_cast<const f4*>(xa + c0 + 4 * q);
             f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // transitions 0..3 of the quad, kGp action pairs each
 #pragma unroll
             for (int p = 0; p < kGp; p++) { za[p] = zb[p] = zc[p] = zd[p] = f2{0.0f, 0.0f}; }
@@ -219,11 +298,23 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                     lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
                     Hn -= zz[k] * lp[k];
                 }
-            const int a_n = action[(size_t)n * G + g];
-            const float Gn = Gs[n];
+            if (!AC && U > 0) {                            // folded over the transitions of state n
+                const long long* row = sga + n * kPad;
+                long long sg = 0;
 #pragma unroll
-            for (int k = 0; k < kPad; k++)
-                zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
+                for (int k = 0; k < kPad; k++) if (k < A) sg += row[k];
+                const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[n];
+#pragma unroll
+                for (int k = 0; k < kPad; k++)
+                    zz[k] = k < A ? (zz[k] * SG - (float)((double)row[k] * 0x1p-40) + cnt * (ent_coef * zz[k] * (lp[k] + Hn))) * invN
+                                  : 0.0f;
+            } else {
+                const int a_n = action[(size_t)n * G + g];
+                const float Gn = Gs[n];
+#pragma unroll
+                for (int k = 0; k < kPad; k++)
+                    zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
+            }
 #pragma unroll
             for (int k4 = 0; k4 < kPad / 4; k4++)
                 *reinterpret_cast<f4*>(dz + tid * kPad + 4 * k4) = f4{zz[4 * k4], zz[4 * k4 + 1], zz[4 * k4 + 2], zz[4 * k4 + 3]};
@@ -231,7 +322,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         __syncthreads();
         // ---- pass B: fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j] for j in {ja, jb}
         for (int i = half; i < cn; i += 2) {
-            const float x = xs[c0 + i];
+            const float x = xa[c0 + i];
             const float pa = __fmaf_rn(w1a, x, b1a), pb = __fmaf_rn(w1b, x, b1b);
             const float ha = fmaxf(pa, 0.0f), hb = fmaxf(pb, 0.0f);
             f2 d[kPad / 2];
@@ -384,7 +475,7 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
     return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
-                            (value_head ? 2 * nx + kH : 0));
+                            (value_head ? 2 * nx + kH : nx + kChunk + kUmax + 8 + 2 * (size_t)kUmax * pad));
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
