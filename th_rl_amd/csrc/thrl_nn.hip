@@ -246,14 +246,20 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     const int NN = U > 0 ? U : N;
     for (int c0 = 0; c0 < NN; c0 += kChunk) {
         const int cn = min(kChunk, NN - c0);
+        const bool sliced = U > 0 && U <= 64;       // few states: split the hidden units over the 4 waves instead
         {   // ---- pass A1: logits (without bias) into dz
-            const f4 x4 = *reinterpret_cast<const f4*>(xa + c0 + 4 * q);
-            f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // transitions 0..3 of the quad, kGp action pairs each
+            // plain: thread = (state quad tid>>2 of 64, action group tid&3), all 256 hidden units;
+            // sliced: thread = (state quad tid&15 of 16, action group (tid>>4)&3, hidden-unit slice tid>>6),
+            //         partial logits to dz[slice][state][k], summed in pass A2
+            const int qq = sliced ? (tid & 15) : q, kk = sliced ? ((tid >> 4) & 3) : kg;
+            const int j0 = sliced ? (tid >> 6) * (kH / 4) : 0, j1 = sliced ? j0 + kH / 4 : kH;
+            const f4 x4 = *reinterpret_cast<const f4*>(xa + c0 + 4 * qq);
+            f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // states 0..3 of the quad, kGp action pairs each
 #pragma unroll
             for (int p = 0; p < kGp; p++) { za[p] = zb[p] = zc[p] = zd[p] = f2{0.0f, 0.0f}; }
-            const float* wrow = W2t + 2 * kGp * kg;
+            const float* wrow = W2t + 2 * kGp * kk;
 #pragma unroll 4
-            for (int j = 0; j < kH; j++) {
+            for (int j = j0; j < j1; j++) {
                 const float w1 = w1s[j], b1 = b1s[j];
                 const float h0 = fmaxf(__fmaf_rn(w1, x4.x, b1), 0.0f), h1 = fmaxf(__fmaf_rn(w1, x4.y, b1), 0.0f);
                 const float h2 = fmaxf(__fmaf_rn(w1, x4.z, b1), 0.0f), h3 = fmaxf(__fmaf_rn(w1, x4.w, b1), 0.0f);
@@ -264,7 +270,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                     zc[p] = pk_fma(wv, f2{h2, h2}, zc[p]); zd[p] = pk_fma(wv, f2{h3, h3}, zd[p]);
                 }
             }
-            float* o = dz + (4 * q) * kPad + 2 * kGp * kg;
+            float* o = dz + (sliced ? (tid >> 6) * 64 * kPad : 0) + (4 * qq) * kPad + 2 * kGp * kk;
 #pragma unroll
             for (int p = 0; p < kGp; p++) {
                 *reinterpret_cast<f2*>(o + 2 * p) = za[p];
@@ -280,7 +286,9 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             float zz[kPad];
 #pragma unroll
             for (int k4 = 0; k4 < kPad / 4; k4++) {
-                const f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
+                f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
+                if (sliced)                                 // add the other three hidden-unit slices, in order
+                    for (int sl = 1; sl < 4; sl++) v += *reinterpret_cast<const f4*>(dz + (sl * 64 + tid) * kPad + 4 * k4);
                 zz[4 * k4] = v.x; zz[4 * k4 + 1] = v.y; zz[4 * k4 + 2] = v.z; zz[4 * k4 + 3] = v.w;
             }
             float m = -INFINITY;
