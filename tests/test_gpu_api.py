@@ -340,3 +340,30 @@ def test_mixed_batch_greedy_play_equals_protocol_play_game():
     for k in range(G):
         np.testing.assert_allclose(mr[0, :, k], d["play%d_rewards" % k].mean(axis=0), rtol=1e-12)
         np.testing.assert_allclose(ma[0, :, k], d["play%d_actions" % k].mean(axis=0), rtol=1e-12)
+
+
+def test_main_cli_runs_a_config_directory(tmp_path):
+    """python -m th_rl_amd.main --dir <configs> --runs 2 (th_rl/main.py:6-23): one run directory per
+    config and run under <dir>/../runs/<config>/<i>, each with the reference's artefacts; a second
+    invocation skips finished configs."""
+    import subprocess
+    import sys
+    cdir = tmp_path / "configs"
+    cdir.mkdir()
+    (cdir / "qq.json").write_text(json.dumps(_config(3, seed=1)))
+    mixed = _config(3, seed=2)
+    mixed["agents"][1] = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4],
+                          "min_memory": 200}
+    (cdir / "qr.json").write_text(json.dumps(mixed))
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-m", "th_rl_amd.main", "--dir", str(cdir), "--runs", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for conf in ("qq", "qr"):
+        for i in ("0", "1"):
+            d = tmp_path / "runs" / conf / i
+            assert (d / "0.npy").exists() and (d / "config.json").exists() and (d / "log.csv").exists()
+    assert (tmp_path / "runs" / "qr" / "0" / "1").exists() and (tmp_path / "runs" / "qq" / "1" / "1_counter.npy").exists()
+    again = subprocess.run([sys.executable, "-m", "th_rl_amd.main", "--dir", str(cdir), "--runs", "2"], env=env,
+                           capture_output=True, text=True, timeout=300)
+    assert again.returncode == 0 and again.stdout.count("Skipping") == 2
