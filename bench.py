@@ -76,8 +76,9 @@ def bench_nn(args):
     from th_rl_amd.mixed import MixedGameBatch
     G = args.games if args.games != (1 << 20) else 65536
     ag = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
-    first = dict(CFG["agents"][0]) if args.nn_agents in ("qr", "qq") else dict(ag)
-    second = dict(CFG["agents"][1]) if args.nn_agents == "qq" else dict(ag)
+    first = dict(ag) if args.nn_agents == "rr" else dict(CFG["agents"][0])
+    second = {"qq": dict(CFG["agents"][1]), "qa": dict(ag, name="ActorCritic", gamma=0.98),
+              "qc": {"name": "CAC", "gamma": 0.98, "states": 1, "action_range": [0.2, 0.4]}}.get(args.nn_agents, dict(ag))
     config = {"agents": [first, second], "environment": dict(CFG["environment"])}
     fused = args.nn_loop == "fused"
     mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=0).init_tables()
@@ -87,7 +88,8 @@ def bench_nn(args):
     mb.run(args.steps, fused=fused)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    who = {"qr": "QTable vs Reinforce", "rr": "2-agent Reinforce", "qq": "2-agent QTable (mixed kernel)"}[args.nn_agents]
+    who = {"qr": "QTable vs Reinforce", "rr": "2-agent Reinforce", "qq": "2-agent QTable (mixed kernel)",
+           "qa": "QTable vs ActorCritic", "qc": "QTable vs CAC"}[args.nn_agents]
     print(json.dumps({"metric": "env-steps/sec, %s (neural policy) x %d games" % (who, G),
                       "value": G * T_STEPS * args.steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -104,7 +106,7 @@ def main():
     ap.add_argument("--games", type=int, default=1 << 20, help="games per GPU")
     ap.add_argument("--chunk", type=int, default=25, help="episodes per kernel launch (<=32)")
     ap.add_argument("--nn-loop", default="fused", choices=["fused", "unfused"])
-    ap.add_argument("--nn-agents", default="rr", choices=["rr", "qr", "qq"])
+    ap.add_argument("--nn-agents", default="rr", choices=["rr", "qr", "qq", "qa", "qc"])
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
     ap.add_argument("--workload", default="qtable", choices=["qtable", "nn"],
                     help="qtable = the headline metric (default); nn = BASELINE configs[3]: 2 Reinforce "
