@@ -178,23 +178,26 @@ void oracle_td_update_f64(double* table, int32_t* counter, int n_actions, int n,
     }
     free(ov);
 }
-/* float32-table variant: same order, every op rounded to float32, constants
- * converted once: (float)(1-alpha), (float)alpha, (float)gamma, (float)reward. */
+/* float32-table variant (the GPU performance path; the reference itself is float64).  The target
+ * (1-alpha)*ov + alpha*(r + gamma*next_max) is evaluated as
+ *     t4 = c1*ov ;  b = fma(af, r, t4) ;  new = fma(af*gf, next_max, b)
+ * with c1 = (float)(1-alpha), af = (float)alpha, gf = (float)gamma, af*gf one rounded float product:
+ * only ONE operation depends on the live next_max, which is what the serial replay chain of the
+ * wave kernel executes per step.  Constants are converted once. */
 void oracle_td_update_f32(float* table, int32_t* counter, int n_actions, int n,
                           const int32_t* st, const int32_t* ac, const double* rw,
                           const int32_t* ns, double alpha, double gamma) {
     float* ov = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     const float c1 = (float)(1.0 - alpha), af = (float)alpha, gf = (float)gamma;
+    const float agf = af * gf;
     for (int k = 0; k < n; k++) ov[k] = table[(size_t)st[k] * n_actions + ac[k]];
     for (int k = 0; k < n; k++) {
         const float* row = table + (size_t)ns[k] * n_actions;
         float nm = row[0];
         for (int j = 1; j < n_actions; j++) if (row[j] > nm) nm = row[j];
         float t4 = c1 * ov[k];
-        float t1 = gf * nm;
-        float t2 = (float)rw[k] + t1;
-        float t3 = af * t2;
-        table[(size_t)st[k] * n_actions + ac[k]] = t4 + t3;
+        float b = fmaf(af, (float)rw[k], t4);
+        table[(size_t)st[k] * n_actions + ac[k]] = fmaf(agf, nm, b);
         if (counter) counter[(size_t)st[k] * n_actions + ac[k]] += 1;
     }
     free(ov);

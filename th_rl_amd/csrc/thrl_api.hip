@@ -82,6 +82,7 @@ void fill_agents(const thrl_cfg* c, AgentParams* ag, EnvParams* env) {
             p.one_minus_alpha = 1.0 - c->alpha[i];
             p.gamma_f = (float)c->gamma[i]; p.alpha_f = (float)c->alpha[i];
             p.one_minus_alpha_f = (float)(1.0 - c->alpha[i]);
+            p.alpha_gamma_f = p.alpha_f * p.gamma_f;
             p.eps_end = c->eps_end[i]; p.eps_step = c->eps_step[i];
             p.act_lo = c->act_lo[i]; p.act_span = c->act_hi[i] - c->act_lo[i];
             p.act_den = (double)c->n_actions[i] - 1.0;

@@ -64,6 +64,7 @@ struct AgentParams {          // one per agent, by value in the kernel argument 
     float   max_state_f;      // weak-scalar cast used by the float32 encode
     double  gamma, alpha, one_minus_alpha;
     float   gamma_f, alpha_f, one_minus_alpha_f;
+    float   alpha_gamma_f;    // alpha_f * gamma_f, one rounded float product
     double  eps_end, eps_step;
     double  act_lo, act_span; // lo, (hi - lo)
     double  act_den;          // actions - 1.0
@@ -114,9 +115,10 @@ __device__ __forceinline__ double td_value(double ov, double re, double nm, cons
     return __dadd_rn(t4, __dmul_rn(p.alpha, t2));
 }
 __device__ __forceinline__ float td_value(float ov, double re, float nm, const AgentParams& p) {
+    // float32 mode (oracle_td_update_f32): one fused op depends on the live next_max
     const float t4 = __fmul_rn(p.one_minus_alpha_f, ov);
-    const float t2 = __fadd_rn((float)re, __fmul_rn(p.gamma_f, nm));
-    return __fadd_rn(t4, __fmul_rn(p.alpha_f, t2));
+    const float b = __fmaf_rn(p.alpha_f, (float)re, t4);
+    return __fmaf_rn(p.alpha_gamma_f, nm, b);
 }
 
 template <typename T>

@@ -233,6 +233,7 @@ k_wave_episodes(const WaveArgs a) {
         double epsg0 = 0.0, epsg1 = 0.0;               // per-game epsilon (sweep mode)
         const bool sw_eps_on = SWEEP && a.sw_eps != nullptr;
         if (sw_eps_on) { epsg0 = a.sw_eps[g]; epsg1 = a.sw_eps[(size_t)a.G + g]; }
+        const float ag_h = __fmul_rn(alpha_h, gamma_h);  // the only coefficient on the replay chain (float32 TD form, thrl_device.h)
         const double eend0 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[g] : p0.eps_end;
         const double eend1 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[(size_t)a.G + g] : p1.eps_end;
         const double estep0 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[g] : p0.eps_step;
@@ -490,31 +491,32 @@ k_wave_episodes(const WaveArgs a) {
                         valid ? act[seg] : 0xFFFFFFFFu;
 
                 // ---- (e) replay chain (agents.py:68-76): live next_max, sequential writes.
-                //      Per step: 3 bpermutes fetch this half's reward / old-value term /
-                //      write address, one ds_read of the next-state row, the half max,
-                //      4 float ops, one masked ds_write.
+                //      Per step: 2 bpermutes fetch this half's next_max-independent part of the
+                //      target and the write address, one ds_read of the next-state row, the half
+                //      max, ONE fma, one masked ds_write.
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
-                    const unsigned re_k = k ? req.y : req.x;
-                    const unsigned t4_k = k ? t4q[seg].y : t4q[seg].x;
+                    // b = fma(alpha, reward, (1-alpha)*old_value): everything of the target that does
+                    // not depend on the live next_max, lane-parallel (lane = step, halves = agents)
+                    const unsigned c1_k = __builtin_bit_cast(unsigned, __fmaf_rn(alpha_h,
+                        __builtin_bit_cast(float, k ? req.y : req.x), __builtin_bit_cast(float, k ? t4q[seg].y : t4q[seg].x)));
                     const unsigned wo_k = k ? woq.y : woq.x;
                     // Operands of step t+1 are fetched while step t's max chain runs: the row
                     // read is issued FIRST (LDS returns in order, so the wait before the max is
-                    // lgkmcnt(3), not 0).  Two steps per iteration so no register rotation.
+                    // lgkmcnt(2), not 0).  Two steps per iteration so no register rotation.
                     unsigned sel = sel_base;
-                    unsigned reA = bperm(sel, re_k), t4A = bperm(sel, t4_k), woA = bperm(sel, wo_k);
-                    unsigned reB = 0, t4B = 0, woB = 0;
+                    unsigned c1A = bperm(sel, c1_k), woA = bperm(sel, wo_k);
+                    unsigned c1B = 0, woB = 0;
                     const int tb = k * 32;
                     for (int t = 0; t < nsub; t += 2) {
                         {
                             const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t));
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
-                            reB = bperm(sel, re_k); t4B = bperm(sel, t4_k); woB = bperm(sel, wo_k);
+                            c1B = bperm(sel, c1_k); woB = bperm(sel, wo_k);
                             const float nm = half_max_upper_row(row_v);
-                            const float val = __fadd_rn(__builtin_bit_cast(float, t4A),
-                                __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reA), __fmul_rn(gamma_h, nm))));
+                            const float val = __fmaf_rn(ag_h, nm, __builtin_bit_cast(float, c1A));
                             if (writer) lds_store_f32(woA, val);
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -522,10 +524,9 @@ k_wave_episodes(const WaveArgs a) {
                             const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t + 1));
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
-                            reA = bperm(sel, re_k); t4A = bperm(sel, t4_k); woA = bperm(sel, wo_k);
+                            c1A = bperm(sel, c1_k); woA = bperm(sel, wo_k);
                             const float nm = half_max_upper_row(row_v);
-                            const float val = __fadd_rn(__builtin_bit_cast(float, t4B),
-                                __fmul_rn(alpha_h, __fadd_rn(__builtin_bit_cast(float, reB), __fmul_rn(gamma_h, nm))));
+                            const float val = __fmaf_rn(ag_h, nm, __builtin_bit_cast(float, c1B));
                             if (writer) lds_store_f32(woB, val);
                             __builtin_amdgcn_wave_barrier();
                         }
