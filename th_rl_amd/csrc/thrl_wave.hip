@@ -479,7 +479,10 @@ k_wave_episodes(const WaveArgs a) {
                 const v2u req = pack_halves(__builtin_bit_cast(unsigned, (float)r0d),
                                             __builtin_bit_cast(unsigned, (float)r1d));
                 const v2u woq = pack_halves(tab0_off + (srow * A + a0) * 4u, tab1_off + (srow * A + a1) * 4u);
-                const uint32_t nsoff = ns * (uint32_t)A * 4u;
+                // next-state row offsets of steps (t, t+1) packed in lane t: one v_readlane per loop
+                // iteration below, the halves are split on the scalar unit
+                const uint32_t nsoff1 = ns * (uint32_t)A * 4u;
+                const uint32_t nsoff = nsoff1 | ((uint32_t)__shfl_down((int)nsoff1, 1, 64) << 16);
                 if (valid) {
                     lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
                     la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
@@ -510,8 +513,9 @@ k_wave_episodes(const WaveArgs a) {
                     unsigned c1B = 0, woB = 0;
                     const int tb = k * 32;
                     for (int t = 0; t < nsub; t += 2) {
+                        const uint32_t off2 = readlane_u(nsoff, tb + t);
                         {
-                            const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t));
+                            const float row_v = lds_load_f32(tabh_col_lds + (off2 & 0xFFFFu));
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
                             c1B = bperm(sel, c1_k); woB = bperm(sel, wo_k);
@@ -521,7 +525,7 @@ k_wave_episodes(const WaveArgs a) {
                             __builtin_amdgcn_wave_barrier();
                         }
                         if (t + 1 < nsub) {
-                            const float row_v = lds_load_f32(tabh_col_lds + readlane_u(nsoff, tb + t + 1));
+                            const float row_v = lds_load_f32(tabh_col_lds + (off2 >> 16));
                             __builtin_amdgcn_sched_barrier(0);
                             sel += 4u;
                             c1A = bperm(sel, c1_k); woA = bperm(sel, wo_k);
