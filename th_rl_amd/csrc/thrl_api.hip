@@ -202,9 +202,9 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
-constexpr size_t kMaxWaves = 256 * 32;          // at most 32 resident waves on each of 256 CUs
+constexpr size_t kMaxWaves = 256 * 64;          // waves of one launch (resident: at most 32 per CU on 256 CUs; the grid may be oversubscribed)
 constexpr size_t kTlogBytesPerWave = (size_t)kWaveMaxEpisodes * 4 * 64 * 4;   // 32 episodes x 4 segments x 64 steps
-constexpr size_t kPartialBytes = kMaxWaves * 4 * kWaveMaxEpisodes * sizeof(double);
+constexpr size_t kPartialBytes = kMaxWaves * 4 * kWaveMaxEpisodes * sizeof(long long);
 
 }  // namespace
 
@@ -323,7 +323,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     if (!b->workspace || b->workspace_bytes < thrl_workspace_bytes(c))
         return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes,
                     thrl_workspace_bytes(c));
-    if (wave_lut_layout(c->n_actions[0]).bytes > (int)kLutRegion) return fail(THRL_ERR_UNSUPPORTED, "LUT image too large");
+    if (wave_lut_layout(c->n_actions[0]).bytes > (int)kLutRegion - 64) return fail(THRL_ERR_UNSUPPORTED, "LUT image too large");
     WaveArgs a;
     memset(&a, 0, sizeof(a));
     a.G = c->n_games; a.T = c->max_steps; a.A = c->n_actions[0]; a.rows = c->n_states[0] + 1;
@@ -337,8 +337,21 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     a.q = (float*)b->q; a.counter = b->counter; a.state = b->state;
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut_ns = lut;
-    a.partial = (double*)((char*)b->workspace + kLutRegion);
+    a.partial = (long long*)((char*)b->workspace + kLutRegion);
+    {   // fixed-point scales of the log sums: 2^s with G * (bound of one game's episode mean) * 2^s <= 2^62
+        double hi = 0.0;
+        for (int i = 0; i < 2; i++) hi = fmax(hi, fmax(fabs(c->act_lo[i]), fabs(c->act_hi[i])));
+        const double bound[2] = {fmax(c->env_a * (c->env_a / c->env_b) * hi, 1e-300), fmax(hi, 1e-300)};
+        for (int k = 0; k < 2; k++) {
+            int ex = 0;
+            frexp((double)c->n_games * bound[k], &ex);          // G*bound < 2^ex
+            int sh = 62 - ex;
+            sh = sh > 60 ? 60 : (sh < 0 ? 0 : sh);
+            a.log_scale[k] = ldexp(1.0, sh);
+        }
+    }
     a.tlog = (uint32_t*)((char*)b->workspace + kLutRegion + kPartialBytes);
+    a.next_game = (int32_t*)((char*)b->workspace + kLutRegion - 64);       // the LUT image is < 16 KiB - 64
     a.seed = run->seed; a.game_offset = run->game_offset;
     a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
     a.sw_eps_step = b->sweep_eps_step; a.sw_eps = b->sweep_eps; a.sw_noise_prob = b->sweep_noise_prob;
@@ -349,7 +362,9 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
 
     const int block = p.waves_per_block * 64;
     int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
-    const int max_grid = num_cu() * p.blocks_per_cu;
+    int grid_mult = 1;                                    // tuning/diagnostic knob: blocks per resident slot
+    if (const char* e = getenv("THRL_WAVE_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 3) grid_mult = v; }
+    const int max_grid = num_cu() * p.blocks_per_cu * grid_mult;
     if (grid > max_grid) grid = max_grid;
     a.total_waves = grid * p.waves_per_block;
     if ((size_t)a.total_waves > kMaxWaves) return fail(THRL_ERR_WORKSPACE, "too many waves for workspace");
@@ -376,10 +391,11 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
                 a.eps[ep][i] = run->eps[i];
                 run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];
             }
+        if (hipMemsetAsync(a.next_game, 0, sizeof(int32_t), s) != hipSuccess) return hip_fail((int)hipGetLastError(), "hipMemsetAsync");
         e = launch_wave(a, grid, block, lds, s);
         if (e) return hip_fail(e, "k_wave_episodes launch");
         if (b->reward_log || b->action_log) {
-            e = launch_wave_reduce(a.partial, a.total_waves, n, c->n_games,
+            e = launch_wave_reduce(a.partial, a.log_scale, a.total_waves, n, c->n_games,
                                    b->reward_log ? b->reward_log + (size_t)done * 2 : nullptr,
                                    b->action_log ? b->action_log + (size_t)done * 2 : nullptr, s);
             if (e) return hip_fail(e, "k_wave_reduce launch");

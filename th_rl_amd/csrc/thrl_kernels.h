@@ -55,8 +55,11 @@ struct WaveArgs {
     int32_t* counter;
     double* state;
     const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
-    double* partial;                // device [total_waves][kWaveMaxEpisodes][4] per-wave log sums
-    uint32_t* tlog;                 // device [total_waves][16 episodes][NSEG][64] packed transitions
+    long long* partial;             // device [total_waves][kWaveMaxEpisodes][4] per-wave log sums, fixed point
+    double log_scale[2];            // fixed-point scales of the (reward, action) log sums: powers of two, sized by the host
+                                    // so that G games cannot overflow 2^62; integer sums are order independent
+    uint32_t* tlog;                 // device [total_waves][32 episodes][NSEG][64] packed transitions
+    int32_t* next_game;             // device: work counter of the launch (games are handed out dynamically), zeroed by the host
     const double* inj_u;            // parity mode: device [n_episodes][T][2][G] uniforms, or null (Philox)
     const int8_t* inj_choice;       // parity mode: device [n_episodes][T][2][G] random.choice indices
     const double* inj_noise_u;      // parity mode with noise: device [n_episodes][T][G]
@@ -72,7 +75,7 @@ int launch_generic(const GenericArgs& a, int q_dtype, hipStream_t s);
 int launch_finalize_logs(double* sum_reward, double* sum_action, int n, int G, hipStream_t s);
 int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s);
 int launch_wave(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
-int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G,
+int launch_wave_reduce(const long long* partial, const double* log_scale, int total_waves, int n_episodes, int G,
                        double* reward_log, double* action_log, hipStream_t s);
 
 struct InitArgs {

@@ -212,10 +212,19 @@ k_wave_episodes(const WaveArgs a) {
     const AgentParams& p1 = a.ag[1];
     const double inv_T_den = (double)T;
 
-    double acc = 0.0, acc_hi = 0.0;   // lane ((e&15)*4+k): sum over this wave's games of episode-e log value k (e < 16 / e >= 16)
+    // lane ((e&15)*4+k): sum over this wave's games of episode-e log value k (e < 16 / e >= 16), as
+    // fixed-point integers: the games a wave gets are not deterministic, integer sums do not care
+    long long acc = 0, acc_hi = 0;
+    const double log_scale = (lane & 2) ? a.log_scale[1] : a.log_scale[0];
     const int wave_gid = blockIdx.x * a.waves_per_block + wib;
 
-    for (int g = wave_gid; g < a.G; g += a.total_waves) {
+    // Games are handed out dynamically (one atomic per game): waves on less crowded CUs simply take
+    // more games, which measured 7-13 % faster than the static grid-stride assignment.
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(a.next_game, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= a.G) break;
         const uint64_t gid = a.game_offset + (uint64_t)g;
         float* __restrict__ q0 = a.q + (int64_t)g * a.stride + p0.table_off;
         float* __restrict__ q1 = a.q + (int64_t)g * a.stride + p1.table_off;
@@ -543,7 +552,8 @@ k_wave_episodes(const WaveArgs a) {
             {
                 double v = wave_sum4(lr0, lr1, la0, la1, lane);
                 if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
-                if ((lane >> 2) == (e & 15)) { if (e < 16) acc += v; else acc_hi += v; }
+                const long long vq = __double2ll_rn(__dmul_rn(v, log_scale));
+                if ((lane >> 2) == (e & 15)) { if (e < 16) acc += vq; else acc_hi += vq; }
             }
             // epsilon decays after every train_net call (agents.py:78)
             if (SWEEP) {
@@ -642,16 +652,17 @@ k_wave_episodes(const WaveArgs a) {
     a.partial[(size_t)wave_gid * 128 + 64 + lane] = acc_hi;
 }
 
-// fixed-order reduction of the per-wave partials -> mean logs [E][2].
-// One block per accumulator slot j = e*4+k; thread i sums waves i, i+256, ... in order,
-// then a fixed-shape LDS tree: the result is deterministic for a given launch geometry.
-__global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int total_waves, int n_episodes,
+// reduction of the per-wave fixed-point partials -> mean logs [E][2].  One block per accumulator
+// slot j = e*4+k.  Integer sums: exact, so the result does not depend on which wave played which
+// game nor on the launch geometry.
+__global__ void __launch_bounds__(256) k_wave_reduce(const long long* partial, double scale_r, double scale_a,
+                                                     int total_waves, int n_episodes,
                                                      double G, double* reward_log, double* action_log) {
-    __shared__ double red[256];
+    __shared__ long long red[256];
     const int j = blockIdx.x;
     const int e = j >> 2, k = j & 3;
     if (e >= n_episodes) return;
-    double s = 0.0;
+    long long s = 0;
     for (int w = threadIdx.x; w < total_waves; w += 256) s += partial[(size_t)w * 128 + j];
     red[threadIdx.x] = s;
     __syncthreads();
@@ -660,7 +671,7 @@ __global__ void __launch_bounds__(256) k_wave_reduce(const double* partial, int 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const double m = __ddiv_rn(red[0], G);
+        const double m = __ddiv_rn(__ddiv_rn((double)red[0], k < 2 ? scale_r : scale_a), G);
         if (k < 2) { if (reward_log) reward_log[e * 2 + k] = m; }
         else { if (action_log) action_log[e * 2 + (k - 2)] = m; }
     }
@@ -707,9 +718,10 @@ int launch_wave(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t 
                                   : launch_wave_n<false, false>(a, grid, block, lds, s);
 }
 
-int launch_wave_reduce(const double* partial, int total_waves, int n_episodes, int G, double* reward_log,
+int launch_wave_reduce(const long long* partial, const double* log_scale, int total_waves, int n_episodes, int G, double* reward_log,
                        double* action_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_wave_reduce, dim3(4 * kWaveMaxEpisodes), dim3(256), 0, s, partial, total_waves, n_episodes, (double)G,
+    hipLaunchKernelGGL(k_wave_reduce, dim3(4 * kWaveMaxEpisodes), dim3(256), 0, s, partial, log_scale[0], log_scale[1],
+                       total_waves, n_episodes, (double)G,
                        reward_log, action_log);
     return (int)hipGetLastError();
 }
