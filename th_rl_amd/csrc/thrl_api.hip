@@ -177,20 +177,25 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     int best_w = 0, best_total = 0, best_b = 0;
     int cap_waves = 32;                                   // tuning/diagnostic knob
     if (const char* e = getenv("THRL_WAVE_MAX_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) cap_waves = v; }
-    // A block's waves are dealt to the CU's 4 SIMDs in turn, and every wave has the same
-    // amount of work, so blocks of 4k waves keep the SIMDs evenly loaded (5-wave blocks
-    // measured 21% slower at MORE resident waves).  Fall back to any size if none fits.
-    for (int pass = 0; pass < 2 && best_w == 0; pass++)
-        for (int w = 1; w <= 16; w++) {
-            if (pass == 0 && (w & 3)) continue;
-            const int lds = p.lut_bytes + w * p.game_lds_bytes;
-            if (lds > 65536) break;
-            int b = 163840 / (((lds + 511) / 512) * 512);
-            if (b * w > cap_waves) b = cap_waves / w;
-            if (b < 1) continue;
-            const int total = b * w;
-            if (total > best_total || (total == best_total && w < best_w)) { best_total = total; best_w = w; best_b = b; }
+    // Most resident waves wins (throughput is latency-bound and scales with them).  A block's waves
+    // are dealt to the CU's 4 SIMDs in turn, so among equal totals blocks of 4k waves are preferred
+    // (they load the SIMDs evenly); with games handed out dynamically an uneven split only costs the
+    // crowded SIMD's waves some speed (noise window: 3 x 5 waves measured 12 % faster than 3 x 4).
+    // register limit: the kernel variants are compiled for 5 waves/SIMD (4 with noise or T > 128)
+    const int reg_waves = 4 * ((c->noise_prob > 0.0 || c->max_steps > 128) ? 4 : 5);
+    if (cap_waves > reg_waves) cap_waves = reg_waves;
+    for (int w = 1; w <= 16; w++) {
+        const int lds = p.lut_bytes + w * p.game_lds_bytes;
+        if (lds > 65536) break;
+        int b = 163840 / (((lds + 511) / 512) * 512);
+        if (b * w > cap_waves) b = cap_waves / w;
+        if (b < 1) continue;
+        const int total = b * w;
+        const bool even = (w & 3) == 0, best_even = best_w > 0 && (best_w & 3) == 0;
+        if (total > best_total || (total == best_total && ((even && !best_even) || (even == best_even && w < best_w)))) {
+            best_total = total; best_w = w; best_b = b;
         }
+    }
     if (best_w == 0) NO("table window does not fit LDS");
     p.waves_per_block = best_w;
     p.blocks_per_cu = best_b;

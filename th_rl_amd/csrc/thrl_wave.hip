@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
 // SWEEP: per-game hyper-parameter arrays (thrl_buffers.sweep_*); compiled only together with NOISE
 // so the headline variant carries none of that state.
 template <int NSEG, int NRSEG, bool NOISE, bool SWEEP>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NOISE ? 3 : (NSEG <= 2 ? 5 : 4))))
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NOISE ? 4 : (NSEG <= 2 ? 5 : 4))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
