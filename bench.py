@@ -224,6 +224,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         # what the HBM actually moved per second (PMC traffic / launch time): tables
+                         # stay in LDS for a whole launch, so it is far below `achieved`
+                         "traffic_gbps": None if traffic is None else traffic / avg_launch_s / 1e9,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches_timed": len(full)},
         }
         if cpu is not None:
