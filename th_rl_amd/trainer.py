@@ -54,6 +54,14 @@ def _progress_line(print_eps, eps, elapsed, e, rew, act, names):
         elapsed, e, numpy.round(100 * rew) / 100, ",".join(names), numpy.round(100 * act) / 100)
 
 
+def resume_is_gamebatch(path):
+    """True when `path` is a checkpoint written by GameBatch (so the continued run must use it too)."""
+    if not path:
+        return False
+    import torch
+    return torch.load(path, weights_only=True).get("kind") != "mixed"
+
+
 def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     if not os.path.exists(exp_path):
         os.mkdir(os.path.join(exp_path))
@@ -75,7 +83,16 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     names = [a["name"] for a in config["agents"]]
 
     resume = training.get("resume", None)
-    if all_tabular:
+    # All-QTable games the LDS-resident wave kernel cannot take (float64 tables -- the default for one
+    # game --, other than 2 agents, per-agent grids, T < min_memory) run one wavefront per game through
+    # the mixed-agent episode kernel while the batch is small: 4.7x (1 game) to 1.3x (16,384 games) the
+    # one-thread-per-game generic kernel, same bits.  Explicit "kernel" / "sweep" keys keep GameBatch.
+    small_tabular = False
+    if all_tabular and "kernel" not in training and not training.get("sweep") and n_games <= 16384 and not resume_is_gamebatch(resume):
+        import ctypes
+        cfg_probe, _ = _lib.cfg_from_config(config, n_games, {"float32": 0, "float64": 1}[str(dtype)])
+        small_tabular = _lib.load().thrl_select_kernel(ctypes.byref(cfg_probe), 0) == _lib.KERNEL_GENERIC
+    if all_tabular and not small_tabular:
         batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
                           seed=seed, game_offset=int(training.get("game_offset", 0)),
                           kernel=training.get("kernel", "auto"), sweep=training.get("sweep", None))
@@ -88,7 +105,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         batch.load(resume)                              # tables, counters, state, epsilon, episode index
     elif n_games == 1:
         state = environment.reset()                     # drawn once, as trainer.py:45
-        if all_tabular:
+        if all_tabular and not small_tabular:
             batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
         else:
             flat = numpy.zeros((1, batch.stride))
