@@ -207,7 +207,7 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
-constexpr size_t kMaxWaves = 256 * 64;          // waves of one launch (resident: at most 32 per CU on 256 CUs; the grid may be oversubscribed)
+constexpr size_t kMaxWaves = 256 * 32;          // at most 32 resident waves on each of 256 CUs
 constexpr size_t kTlogBytesPerWave = (size_t)kWaveMaxEpisodes * 4 * 64 * 4;   // 32 episodes x 4 segments x 64 steps
 constexpr size_t kPartialBytes = kMaxWaves * 4 * kWaveMaxEpisodes * sizeof(long long);
 
@@ -367,9 +367,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
 
     const int block = p.waves_per_block * 64;
     int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
-    int grid_mult = 1;                                    // tuning/diagnostic knob: blocks per resident slot
-    if (const char* e = getenv("THRL_WAVE_GRID_MULT")) { int v = atoi(e); if (v >= 1 && v <= 3) grid_mult = v; }
-    const int max_grid = num_cu() * p.blocks_per_cu * grid_mult;
+    const int max_grid = num_cu() * p.blocks_per_cu;      // persistent grid; games are handed out by a work counter
     if (grid > max_grid) grid = max_grid;
     a.total_waves = grid * p.waves_per_block;
     if ((size_t)a.total_waves > kMaxWaves) return fail(THRL_ERR_WORKSPACE, "too many waves for workspace");
