@@ -250,36 +250,43 @@ class MixedGameBatch:
         idx = (torch.arange(n, device=self.device) + start) % cap
         return n, {k: v.index_select(0, idx).contiguous() for k, v in b.items()}
 
-    def run(self, n_episodes, fused=None):
+    def run(self, n_episodes, fused=None, per_game_logs=True):
         """n_episodes for all games.  fused=True: thrl_mixed_episodes, one launch per run of episodes
         between network updates; fused=False: the per-call operator loop (same results); None
         (default): fused unless the library reports the configuration as unsupported by that kernel
         (more than two Reinforce / ActorCritic agents, tables beyond 64 KiB of LDS per game, > 64 actions)."""
         if fused is None:
             try:
-                return self._run_fused(int(n_episodes))
+                return self._run_fused(int(n_episodes), per_game_logs)
             except ThrlError as e:
                 if e.code != _lib.ERR_UNSUPPORTED:
                     raise
                 return self._run_unfused(int(n_episodes))      # nothing was launched: state is untouched
         if fused:
-            return self._run_fused(int(n_episodes))
+            return self._run_fused(int(n_episodes), per_game_logs)
         return self._run_unfused(int(n_episodes))
 
-    def _run_fused(self, E):
+    def _run_fused(self, E, per_game_logs=True):
+        """per_game_logs=False keeps only the mean over games (reduced on the device, launch by launch):
+        what train_one needs, without E x N x G arrays crossing to the host."""
         torch = _torch()
         if not self.initialized:
             raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
         N, G, T = self.N, self.G, self.T
+        kmax = E if per_game_logs else max(1, (1 << 25) // (N * G))      # <= 256 MiB per log buffer
         with torch.cuda.device(self.device):
-            rlog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
-            alog = torch.zeros((E, N, G), dtype=torch.float64, device=self.device)
+            rows = E if per_game_logs else min(E, kmax)
+            rlog = torch.zeros((rows, N, G), dtype=torch.float64, device=self.device)
+            alog = torch.zeros((rows, N, G), dtype=torch.float64, device=self.device)
+            rmean = torch.zeros((E, N), dtype=torch.float64, device=self.device)
+            amean = torch.zeros((E, N), dtype=torch.float64, device=self.device)
             if not hasattr(self, "_scratch"):
                 self._scratch = [torch.zeros_like(b["price"]) if self.kinds[i] == "QTable" else None
                                  for i, b in enumerate(self.buf)]
             done = 0
             while done < E:
-                k = E - done
+                k = min(E - done, kmax)
+                base = done if per_game_logs else 0
                 for i in range(N):                     # stop where a network update is due
                     if self.kinds[i] != "QTable" and self.buf_len[i] > 0 and self.buf_len[i] >= self.min_memory[i]:
                         have = min(self.count[i], self.buf_len[i])
@@ -302,8 +309,10 @@ class MixedGameBatch:
                     r.eps[i] = self.eps[i]
                 _lib.check(self.L.thrl_mixed_episodes(ctypes.byref(self.cfg), ctypes.byref(mx), self._p(self.q),
                                                       self._p(self.counter), self._p(self.state), ctypes.byref(r),
-                                                      self._p(rlog[done:]), self._p(alog[done:]), self._stream()),
+                                                      self._p(rlog[base:]), self._p(alog[base:]), self._stream()),
                            "thrl_mixed_episodes")
+                rmean[done:done + k] = rlog[base:base + k].mean(dim=2)
+                amean[done:done + k] = alog[base:base + k].mean(dim=2)
                 self.eps = [r.eps[i] for i in range(N)] + self.eps[N:]
                 self.count = [mx.count[i] for i in range(N)]
                 self.episode += k
@@ -315,9 +324,9 @@ class MixedGameBatch:
                             self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"])
                             self.count[i] = 0
             torch.cuda.synchronize(self.device)
-            out = dict(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy(), kernel="mixed-fused")
-        out["reward_log"] = out["game_reward_log"].mean(axis=2)
-        out["action_log"] = out["game_action_log"].mean(axis=2)
+            out = dict(kernel="mixed-fused", reward_log=rmean.cpu().numpy(), action_log=amean.cpu().numpy())
+            if per_game_logs:
+                out.update(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy())
         return out
 
     def _run_unfused(self, n_episodes):

@@ -126,7 +126,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     chunk = max(1, int(print_freq)) if print_freq else epochs
     while done < epochs:
         n = min(chunk - (done % chunk), epochs - done)
-        out = batch.run(n)
+        out = batch.run(n) if isinstance(batch, GameBatch) else batch.run(n, per_game_logs=False)
         rewards_log[done:done + n] = out["reward_log"]
         actions_log[done:done + n] = out["action_log"]
         done += n
