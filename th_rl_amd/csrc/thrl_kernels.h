@@ -137,7 +137,7 @@ struct MixedArgs {
     int32_t n_r; int32_t ragent[2];                                    // the (at most 2) Reinforce agents
     int32_t lds_off[THRL_MAXA];                                        // QTable: element offset of the table in LDS; CAC: float offset
     int32_t lds_bytes;
-    int32_t memo_lds_byte0, memo_on;                                   // memoised policy CDFs [n_r][64][APAD] floats
+    int32_t memo_lds_byte0, memo_on, memo_k;                                   // memoised policy CDFs [n_r][64][APAD] floats
     int32_t n_cac, cac_lds_byte0;                                      // CAC networks (kind 3) live in LDS after the tables
 };
 // fills n_r / ragent / lds_off / lds_bytes; returns 0 or -1 with a reason when the config does not fit

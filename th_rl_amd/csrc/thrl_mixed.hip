@@ -17,7 +17,7 @@
 namespace thrl {
 namespace {
 
-constexpr int kMemo = 64;          // memoised policy CDFs per network (one lane of the tag register each)
+constexpr int kMemo = 64;          // at most this many memoised policy CDFs per network (one lane of the tag register each)
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
@@ -137,19 +137,20 @@ k_mixed_wave(const MixedArgs a) {
                 const unsigned key = __float_as_uint(x);
                 unsigned& tag = r == 0 ? tag0 : tag1;
                 int& nmemo = r == 0 ? nmemo0 : nmemo1;
-                float* memo = lds_memo + r * kMemo * APAD;
-                const unsigned long long found = MEMO ? __ballot(tag == key && lane < min(nmemo, kMemo)) : 0ull;
+                const int K = a.memo_k;                                      // entries in use (<= kMemo)
+                float* memo = lds_memo + r * K * APAD;
+                const unsigned long long found = MEMO ? __ballot(tag == key && lane < min(nmemo, K)) : 0ull;
                 float c;
                 if (MEMO && found) {
                     c = memo[(int)__builtin_ctzll(found) * APAD + min(lane >> 1, APAD - 1)];
                 } else {
                     c = policy_cdf(policy_probs(r == 0 ? net0 : net1, A, x, lane));
                     if (MEMO) {
-                        const int slot = nmemo & (kMemo - 1);                // round-robin replacement
+                        const int slot = nmemo >= K ? nmemo - K : nmemo;     // round-robin replacement
                         if (!(lane & 1) && (lane >> 1) < APAD) memo[slot * APAD + (lane >> 1)] = c;
                         if (lane == slot) tag = key;
                         nmemo += 1;
-                        if (nmemo >= 2 * kMemo) nmemo -= kMemo;
+                        if (nmemo >= 2 * K) nmemo -= K;
                     }
                 }
                 int aa = policy_pick(c, (float)u01_32(xu), A, lane);
@@ -324,23 +325,33 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
     for (int i = 0; i < a.N; i++)
         if (a.kind[i] == 3) { a.lds_off[i] = a.n_cac * ((kCacP + 3) & ~3); a.n_cac++; }
     a.lds_bytes += a.n_cac * ((kCacP + 3) & ~3) * 4;
-    // Policy memo only where it can pay: every agent discrete, little env noise, and at most kMemo
-    // distinct float32 prices over the whole action product (2 agents on the same grid: 41).
+    // Policy memo only where it pays: every agent discrete, little env noise, and the whole price
+    // grid (distinct float32 prices over the action product; two agents on the same grid: 41) fits
+    // the entries the LDS leaves at the occupancy the registers allow anyway (12 waves/CU with one
+    // network, 8 with two).  A grid that does not fit was measured: QTable vs Reinforce has 441
+    // prices, a 40-entry memo hits ~35 % of the steps early in training and the lookups cost more
+    // than that saves (9.8 vs 9.2 ms per episode of 65,536 games), so it stays off there.
     a.memo_lds_byte0 = a.lds_bytes;
-    a.memo_on = 0;
+    a.memo_on = 0; a.memo_k = 0;
     if (a.n_r > 0 && a.n_cac == 0 && a.env.noise_prob <= 0.1) {
         long combos = 1;
         for (int i = 0; i < a.N && combos <= 4096; i++) combos *= a.ag[i].n_actions;
-        if (combos <= 4096) {
+        int amax = 0;
+        for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
+        const int entry = (amax <= 24 ? 24 : 32) * 4 * a.n_r;                 // bytes per memo entry over all networks
+        const int budget = 163840 / (a.n_r == 1 ? 12 : 8) - a.lds_bytes;
+        int k = budget / entry;
+        k = k > kMemo ? kMemo : (k & ~7);
+        if (combos <= 4096 && k >= 16) {
             float seen[kMemo + 1];
             int n_seen = 0;
-            int k[THRL_MAXA] = {0};
-            for (long c = 0; c < combos && n_seen <= kMemo; c++) {
+            int kk[THRL_MAXA] = {0};
+            for (long c = 0; c < combos && n_seen <= k; c++) {
                 double Q = 0.0;
                 for (int i = 0; i < a.N; i++) {
                     const AgentParams& p = a.ag[i];
                     const double den = a.kind[i] == 0 ? p.act_den : (double)p.n_actions;   // QTable / Reinforce scale
-                    Q = Q + a.env.ratio * ((double)k[i] / den * p.act_span + p.act_lo);
+                    Q = Q + a.env.ratio * ((double)kk[i] / den * p.act_span + p.act_lo);
                 }
                 double pr = a.env.a - a.env.b * Q;
                 if (!(pr > 0.0)) pr = 0.0;
@@ -348,15 +359,10 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
                 int j = 0;
                 while (j < n_seen && seen[j] != x) j++;
                 if (j == n_seen) seen[n_seen++] = x;
-                for (int i = 0; i < a.N; i++) { if (++k[i] < a.ag[i].n_actions) break; k[i] = 0; }
+                for (int i = 0; i < a.N; i++) { if (++kk[i] < a.ag[i].n_actions) break; kk[i] = 0; }
             }
-            a.memo_on = n_seen <= kMemo;
+            if (n_seen <= k) { a.memo_on = 1; a.memo_k = k; a.lds_bytes += k * entry; }
         }
-    }
-    if (a.memo_on) {
-        int amax = 0;
-        for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
-        a.lds_bytes += a.n_r * kMemo * (amax <= 24 ? 24 : 32) * 4;
     }
     if (a.lds_bytes > 64 * 1024) { *why = "tables and CAC networks of one game exceed 64 KiB of LDS"; return -1; }
     return 0;
