@@ -98,7 +98,9 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     float* xu = reinterpret_cast<float*>(uid + NX);         // [kChunk] the distinct states, zero padded
     int* ucnt = reinterpret_cast<int*>(xu + kChunk);        // [kUmax] transitions per distinct state
     int* redi = ucnt + kUmax;                               // [8]
-    long long* sga = reinterpret_cast<long long*>(redi + 8);   // [kUmax][kPad] sum of returns by (state, action), 2^-40 fixed point
+    unsigned* hkeys = reinterpret_cast<unsigned*>(redi + 8);   // [256] hash table of the distinct states (float bits)
+    int* hrank = reinterpret_cast<int*>(hkeys + 256);       // [256] slot -> index of the state in ascending order
+    long long* sga = reinterpret_cast<long long*>(hrank + 256);   // [kUmax][kPad] sum of returns by (state, action), 2^-40 fixed point
     const int g = blockIdx.x, tid = threadIdx.x;
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
@@ -152,39 +154,54 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             xu[tid] = 0.0f;
             if (tid < kUmax) ucnt[tid] = 0;
             for (int k = tid; k < kUmax * kPad; k += 256) sga[k] = 0;
-            int round = 0;
-            bool hopeless = false;
-            for (; round < kUmax; round++) {
-                if (round == 8) {        // 8 states cover less than an eighth of the batch: too many states, stop
-                    int open_n = __popc(open_mask);
+            // distinct states by open addressing in a 256-slot LDS table (key = the float32 state's
+            // bits), then numbered by ascending key so the numbering -- and with it the order of
+            // every later sum -- does not depend on which thread won which slot
+            constexpr unsigned kEmpty = 0xFFFFFFFFu;
+            hkeys[tid] = kEmpty;
+            if (tid < 8) redi[tid] = 0;
+            __syncthreads();
+            int myslot[kOwn];
+            bool lost = false;
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) open_n += __shfl_xor(open_n, o, 64);
-                    __syncthreads();
-                    if ((tid & 63) == 0) redi[4 + (tid >> 6)] = open_n;
-                    __syncthreads();
-                    if (redi[4] + redi[5] + redi[6] + redi[7] > N - N / 8) { hopeless = true; break; }
+            for (int q2 = 0; q2 < kOwn; q2++) {
+                myslot[q2] = 0;
+                if ((open_mask >> q2) & 1u) {
+                    const unsigned bits = __float_as_uint(xq[q2]);
+                    unsigned h = (bits * 2654435761u) >> 24;
+                    int probe = 0;
+                    for (; probe < 256; probe++) {
+                        if (redi[5] > kUmax) { probe = 256; break; }        // too many states already: plain path
+                        const unsigned old = atomicCAS(&hkeys[h], kEmpty, bits);
+                        if (old == kEmpty) atomicAdd(&redi[5], 1);
+                        if (old == kEmpty || old == bits) break;
+                        h = (h + 1) & 255u;
+                    }
+                    lost |= probe == 256;
+                    myslot[q2] = (int)h;
                 }
-                int cand = open_mask ? tid + 256 * (__ffs((int)open_mask) - 1) : 0x7fffffff;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-                __syncthreads();
-                if ((tid & 63) == 0) redi[tid >> 6] = cand;
-                __syncthreads();
-                const int first = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
-                if (first == 0x7fffffff) break;                       // every transition has its state
-                const float xr = xs[first];
-                if (tid == 0) xu[round] = xr;
-#pragma unroll
-                for (int q2 = 0; q2 < kOwn; q2++)
-                    if (((open_mask >> q2) & 1u) && xq[q2] == xr) { uid[tid + 256 * q2] = round; open_mask &= ~(1u << q2); }
             }
             __syncthreads();
-            if ((tid & 63) == 0) redi[4 + (tid >> 6)] = 0;
+            const unsigned mykey = hkeys[tid];
+            const unsigned long long occ = __ballot(mykey != kEmpty);
+            if ((tid & 63) == 0) redi[tid >> 6] = __popcll(occ);
+            if (lost) redi[4] = 1;
             __syncthreads();
-            if (open_mask) redi[4 + (tid >> 6)] = 1;
-            __syncthreads();
-            const bool leftover = (redi[4] | redi[5] | redi[6] | redi[7]) != 0;
-            U = (leftover || hopeless) ? 0 : round;
+            const int n_states = redi[0] + redi[1] + redi[2] + redi[3];
+            U = (redi[4] != 0 || n_states > kUmax) ? 0 : n_states;
+            if (U > 0) {
+                if (mykey != kEmpty) {
+                    int r = 0;
+                    for (int sl = 0; sl < 256; sl++) r += hkeys[sl] < mykey ? 1 : 0;     // kEmpty is the largest value
+                    hrank[tid] = r;
+                    xu[r] = __uint_as_float(mykey);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++)
+                    if ((open_mask >> q2) & 1u) uid[tid + 256 * q2] = hrank[myslot[q2]];
+                __syncthreads();
+            }
             if (U > 0) {
 #pragma unroll
                 for (int q2 = 0; q2 < kOwn; q2++) {
@@ -483,7 +500,7 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
     return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
-                            (value_head ? 2 * nx + kH : nx + kChunk + kUmax + 8 + 2 * (size_t)kUmax * pad));
+                            (value_head ? 2 * nx + kH : nx + kChunk + kUmax + 8 + 512 + 2 * (size_t)kUmax * pad));
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
