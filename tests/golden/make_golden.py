@@ -300,6 +300,25 @@ def golden_td():
     return out
 
 
+def random_config(k):
+    """G6: seeded random configurations (2-4 agents, per-agent grids / table sizes / max_state, ragged
+    T, min_memory and capacity, env noise) -- the reference run on shapes nobody picked by hand."""
+    rs = numpy.random.RandomState(600 + k)
+    n = int(rs.choice([2, 2, 3, 4]))
+    T = int(rs.choice([7, 12, 25, 40]))
+    agents = []
+    for _ in range(n):
+        lo = float(numpy.round(rs.uniform(0.0, 0.3), 2))
+        agents.append(dict(name="QTable", gamma=float(rs.choice([0.35, 0.9, 0.95])), actions=int(rs.choice([3, 7, 21, 30])),
+                           states=int(rs.choice([16, 40, 100])), alpha=float(rs.choice([0.05, 0.1, 0.5])), eps_end=0.02,
+                           epsilon=float(rs.choice([0.2, 0.5, 1.0])), eps_step=float(rs.choice([0.9, 0.999])),
+                           action_range=[lo, float(numpy.round(lo + rs.uniform(0.05, 0.12), 2))],
+                           max_state=float(rs.choice([10, 12])), min_memory=int(rs.choice([1, T, T + 3, 2 * T])),
+                           capacity=int(rs.choice([T + 1, 2 * T + 5, 500]))))
+    env = dict(name="NoisyPriceState", noise_prob=float(rs.choice([0.0, 0.05, 0.4])), a=10, b=1, nplayers=n, max_steps=T)
+    return make_config(agents, env, int(rs.choice([6, 9, 12])))
+
+
 def main():
     os.makedirs(HERE, exist_ok=True)
 
@@ -307,6 +326,11 @@ def main():
         p = os.path.join(HERE, name)
         numpy.savez_compressed(p, **d)
         print("wrote", p, os.path.getsize(p), "bytes")
+
+    if "--only-g6" in sys.argv:
+        for k in range(6):
+            save("g6_random%d_seed%d.npz" % (k, 60 + k), run_reference(random_config(k), 60 + k))
+        return
 
     save("g1_payoff_grid.npz", golden_payoff_grid())
     save("g2_encode.npz", golden_encode())
@@ -345,6 +369,8 @@ def main():
            dict(CFG_AGENT, actions=5, states=20, action_range=[0.0, 0.4], min_memory=25, max_state=8)]
     cfg = make_config(ags, env3, 30)
     save("g5_three_players_seed9_e30.npz", run_reference(cfg, 9))
+    for k in range(6):
+        save("g6_random%d_seed%d.npz" % (k, 60 + k), run_reference(random_config(k), 60 + k))
 
 
 if __name__ == "__main__":

@@ -39,7 +39,7 @@ def _oracle_run(config, G, q_dtype, q, state, E, seed=0, game_offset=0, first_ep
 
 
 def _traj_files():
-    return sorted(glob.glob(os.path.join(GOLDEN, "g4_*.npz")) + glob.glob(os.path.join(GOLDEN, "g5_*.npz")))
+    return sorted(glob.glob(os.path.join(GOLDEN, "g4_*.npz")) + glob.glob(os.path.join(GOLDEN, "g5_*.npz")) + glob.glob(os.path.join(GOLDEN, "g6_*.npz")))
 
 
 @pytest.mark.parametrize("path", _traj_files(), ids=os.path.basename)

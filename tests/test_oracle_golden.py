@@ -94,7 +94,7 @@ def test_g3_td_known_answers(name):
 
 
 def _traj_files():
-    return sorted(glob.glob(os.path.join(GOLDEN, "g4_*.npz")) + glob.glob(os.path.join(GOLDEN, "g5_*.npz")))
+    return sorted(glob.glob(os.path.join(GOLDEN, "g4_*.npz")) + glob.glob(os.path.join(GOLDEN, "g5_*.npz")) + glob.glob(os.path.join(GOLDEN, "g6_*.npz")))
 
 
 def run_oracle_on_golden(d, q_dtype=1, n_episodes=None):
