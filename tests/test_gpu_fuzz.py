@@ -25,14 +25,15 @@ def _random_config(rs):
                  states=int(rs.choice([10, 50, 100, 120])), alpha=float(rs.choice([0.05, 0.1, 0.3])),
                  eps_end=0.001, epsilon=float(rs.choice([0.1, 0.5, 0.9])), eps_step=0.999,
                  action_range=[lo, float(np.round(lo + rs.uniform(0.05, 0.25), 2))],
-                 min_memory=int(rs.choice([1, T // 2 + 1, T, 2 * T + 3])), capacity=int(rs.choice([T + 5, 3 * T, 500])))
+                 min_memory=int(rs.choice([1, T // 2 + 1, T, 2 * T + 3])),
+                 capacity=int(rs.choice([max(2, T // 2), T + 5, 3 * T, 500])))
         base = a
         agents.append(a)
     env = dict(name="NoisyPriceState", noise_prob=float(rs.choice([0.0, 0.0, 0.1, 0.5])), a=10, b=1, nplayers=n, max_steps=T)
     return {"agents": agents, "environment": env}
 
 
-@pytest.mark.parametrize("case", range(14))
+@pytest.mark.parametrize("case", range(20))
 def test_random_config_all_paths_agree(case):
     from th_rl_amd.batched import GameBatch
     from th_rl_amd.mixed import MixedGameBatch
