@@ -585,11 +585,12 @@ def test_example_config_learning_statistics_match_the_reference():
         assert np.all(np.abs(mine - mean) <= 3 * se + 0.01 * np.abs(mean)), (name, mine, mean, se)
 
 
-@pytest.mark.parametrize("distinct", [3, 64, 65, 500])
+@pytest.mark.parametrize("distinct", [3, 64, 65, 130, 320, 321, 500])
 def test_reinforce_update_state_dedupe_and_plain_path(distinct):
-    """The update folds transitions that share a state (<= 64 distinct states per batch) and takes the
-    plain per-transition path beyond that; both against the numpy oracle, and deterministic."""
-    G, n = 6, 500
+    """The update folds transitions that share a state (up to 320 distinct states per batch, 64 per
+    chunk) and takes the plain per-transition path beyond that; all against the numpy oracle, and
+    deterministic."""
+    G, n = 6, 700
     rs = np.random.RandomState(distinct)
     grid = np.sort(rs.uniform(2.0, 6.0, distinct))
     price = grid[rs.randint(0, distinct, (n, G))]

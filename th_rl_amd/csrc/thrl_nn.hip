@@ -64,7 +64,9 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
 //            halves are added through LDS after the last chunk.
 // Rows of fc_pi^T and of dz are padded to kPad = 24 or 32 floats (zero) for aligned vector LDS reads.
 constexpr int kChunk = 256;
-constexpr int kUmax = 64;          // state dedupe: at most this many distinct states per update
+constexpr int kUmax = 64;          // state folding: distinct states handled per chunk
+constexpr int kUfold = 320;        // ... and per update (beyond that: the plain per-transition path)
+constexpr int kHash = 512;         // slots of the LDS table that finds them
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -94,13 +96,13 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     float* gvs = xps + (AC ? NX : 0);                       // [NX]  c_i, then d loss/d v_i (AC only)
     float* wvs = gvs + (AC ? NX : 0);                       // [kH]  fc_v.weight            (AC only)
     // Reinforce only: state dedupe (see below)
-    int* uid = reinterpret_cast<int*>(red + 8);             // [NX]  index of the transition's distinct state
-    float* xu = reinterpret_cast<float*>(uid + NX);         // [kChunk] the distinct states, zero padded
-    int* ucnt = reinterpret_cast<int*>(xu + kChunk);        // [kUmax] transitions per distinct state
+    unsigned short* uid = reinterpret_cast<unsigned short*>(red + 8);   // [NX]  index of the transition's distinct state
+    float* xu = reinterpret_cast<float*>(uid + NX);         // [kHash] the distinct states in ascending order, zero padded
+    int* ucnt = reinterpret_cast<int*>(xu + kHash);         // [kUmax] transitions per state of the current chunk
     int* redi = ucnt + kUmax;                               // [8]
-    unsigned* hkeys = reinterpret_cast<unsigned*>(redi + 8);   // [256] hash table of the distinct states (float bits)
-    int* hrank = reinterpret_cast<int*>(hkeys + 256);       // [256] slot -> index of the state in ascending order
-    long long* sga = reinterpret_cast<long long*>(hrank + 256);   // [kUmax][kPad] sum of returns by (state, action), 2^-40 fixed point
+    unsigned* hkeys = reinterpret_cast<unsigned*>(redi + 8);   // [kHash] hash table of the distinct states (float bits)
+    unsigned short* hrank = reinterpret_cast<unsigned short*>(hkeys + kHash);   // [kHash] slot -> index of the state
+    long long* sga = reinterpret_cast<long long*>(hrank + kHash);   // [kUmax][kPad] returns by (state, action) of the chunk, 2^-40 fixed point
     const int g = blockIdx.x, tid = threadIdx.x;
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
@@ -140,7 +142,8 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         // with SG_u = sum of returns, SGA_u[k] = sum of returns of the transitions that took action k.
         // Passes A and B then run over the U distinct states instead of the n transitions.  The sums
         // are accumulated in 2^-40 fixed point with integer LDS atomics: order independent, so the
-        // update stays deterministic.  More than kUmax distinct states: the plain path.
+        // update stays deterministic.  The states are taken kUmax at a time; more than kUfold distinct
+        // states: the plain path.
         {
             constexpr int kOwn = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
             float xq[kOwn];
@@ -151,14 +154,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                 xq[q2] = n < N ? xs[n] : 0.0f;
                 if (n < N) open_mask |= 1u << q2;
             }
-            xu[tid] = 0.0f;
-            if (tid < kUmax) ucnt[tid] = 0;
-            for (int k = tid; k < kUmax * kPad; k += 256) sga[k] = 0;
-            // distinct states by open addressing in a 256-slot LDS table (key = the float32 state's
+            xu[tid] = 0.0f; xu[tid + 256] = 0.0f;
+            // distinct states by open addressing in a kHash-slot LDS table (key = the float32 state's
             // bits), then numbered by ascending key so the numbering -- and with it the order of
             // every later sum -- does not depend on which thread won which slot
             constexpr unsigned kEmpty = 0xFFFFFFFFu;
-            hkeys[tid] = kEmpty;
+            hkeys[tid] = kEmpty; hkeys[tid + 256] = kEmpty;
             if (tid < 8) redi[tid] = 0;
             __syncthreads();
             int myslot[kOwn];
@@ -168,51 +169,54 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                 myslot[q2] = 0;
                 if ((open_mask >> q2) & 1u) {
                     const unsigned bits = __float_as_uint(xq[q2]);
-                    unsigned h = (bits * 2654435761u) >> 24;
+                    unsigned h = (bits * 2654435761u) >> 23;
                     int probe = 0;
-                    for (; probe < 256; probe++) {
-                        if (redi[5] > kUmax) { probe = 256; break; }        // too many states already: plain path
+                    for (; probe < kHash; probe++) {
+                        if (redi[5] > kUfold) { probe = kHash; break; }      // too many states already: plain path
                         const unsigned old = atomicCAS(&hkeys[h], kEmpty, bits);
                         if (old == kEmpty) atomicAdd(&redi[5], 1);
                         if (old == kEmpty || old == bits) break;
-                        h = (h + 1) & 255u;
+                        h = (h + 1) & (kHash - 1);
                     }
-                    lost |= probe == 256;
+                    lost |= probe == kHash;
                     myslot[q2] = (int)h;
                 }
             }
             __syncthreads();
-            const unsigned mykey = hkeys[tid];
-            const unsigned long long occ = __ballot(mykey != kEmpty);
-            if ((tid & 63) == 0) redi[tid >> 6] = __popcll(occ);
+            const unsigned key_a = hkeys[tid], key_b = hkeys[tid + 256];
+            const unsigned long long occ_a = __ballot(key_a != kEmpty), occ_b = __ballot(key_b != kEmpty);
+            if ((tid & 63) == 0) { ucnt[tid >> 6] = __popcll(occ_a); ucnt[4 + (tid >> 6)] = __popcll(occ_b); }
             if (lost) redi[4] = 1;
             __syncthreads();
-            const int n_states = redi[0] + redi[1] + redi[2] + redi[3];
-            U = (redi[4] != 0 || n_states > kUmax) ? 0 : n_states;
+            int n_states = 0, before_a = 0, before_b = 0;
+#pragma unroll
+            for (int wv = 0; wv < 8; wv++) {
+                const int c = ucnt[wv];
+                if (wv < (tid >> 6)) before_a += c;
+                if (wv < 4 + (tid >> 6)) before_b += c;
+                n_states += c;
+            }
+            // fold only where it is cheaper: ~5 units per 64 states against ~16 per 256 transitions
+            const bool pays = ((n_states + 63) / 64) * 5 + 2 < ((N + kChunk - 1) / kChunk) * 16;
+            U = (redi[4] != 0 || n_states > kUfold || !pays) ? 0 : n_states;
             if (U > 0) {
-                if (mykey != kEmpty) {
-                    int r = 0;
-                    for (int sl = 0; sl < 256; sl++) r += hkeys[sl] < mykey ? 1 : 0;     // kEmpty is the largest value
-                    hrank[tid] = r;
-                    xu[r] = __uint_as_float(mykey);
+                // keys packed densely (in slot order), then ranked by value over the U of them
+                unsigned* dense = reinterpret_cast<unsigned*>(dz);
+                const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+                if (key_a != kEmpty) dense[before_a + __popcll(occ_a & lt)] = key_a;
+                if (key_b != kEmpty) dense[before_b + __popcll(occ_b & lt)] = key_b;
+                __syncthreads();
+                int ra = 0, rb = 0;
+                for (int j = 0; j < U; j++) {
+                    const unsigned kj = dense[j];
+                    ra += kj < key_a ? 1 : 0; rb += kj < key_b ? 1 : 0;
                 }
+                if (key_a != kEmpty) { hrank[tid] = (unsigned short)ra; xu[ra] = __uint_as_float(key_a); }
+                if (key_b != kEmpty) { hrank[tid + 256] = (unsigned short)rb; xu[rb] = __uint_as_float(key_b); }
                 __syncthreads();
 #pragma unroll
                 for (int q2 = 0; q2 < kOwn; q2++)
                     if ((open_mask >> q2) & 1u) uid[tid + 256 * q2] = hrank[myslot[q2]];
-                __syncthreads();
-            }
-            if (U > 0) {
-#pragma unroll
-                for (int q2 = 0; q2 < kOwn; q2++) {
-                    const int n = tid + 256 * q2;
-                    if (n < N) {
-                        const int u = uid[n];
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[(size_t)n * G + g]]),
-                                  (unsigned long long)llrint((double)Gs[n] * 1099511627776.0));
-                        atomicAdd(&ucnt[u], 1);
-                    }
-                }
             }
         }
     } else {
@@ -261,9 +265,25 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
 
     const float* xa = U > 0 ? xu : xs;                      // the states the passes run over
     const int NN = U > 0 ? U : N;
-    for (int c0 = 0; c0 < NN; c0 += kChunk) {
-        const int cn = min(kChunk, NN - c0);
-        const bool sliced = U > 0 && U <= 64;       // few states: split the hidden units over the 4 waves instead
+    const int cstep = U > 0 ? kUmax : kChunk;               // folded: 64 states per chunk; plain: 256 transitions
+    for (int c0 = 0; c0 < NN; c0 += cstep) {
+        const int cn = min(cstep, NN - c0);
+        const bool sliced = U > 0;                  // 64 states: split the hidden units over the 4 waves instead
+        if (!AC && U > 0) {
+            // returns of this chunk's states by (state, action), and their transition counts
+            if (tid < kUmax) ucnt[tid] = 0;
+            for (int k = tid; k < kUmax * kPad; k += 256) sga[k] = 0;
+            __syncthreads();
+            for (int n = tid; n < N; n += 256) {
+                const int u = (int)uid[n] - c0;
+                if (u >= 0 && u < cn) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[(size_t)n * G + g]]),
+                              (unsigned long long)llrint((double)Gs[n] * 1099511627776.0));
+                    atomicAdd(&ucnt[u], 1);
+                }
+            }
+            __syncthreads();
+        }
         {   // ---- pass A1: logits (without bias) into dz
             // plain: thread = (state quad tid>>2 of 64, action group tid&3), all 256 hidden units;
             // sliced: thread = (state quad tid&15 of 16, action group (tid>>4)&3, hidden-unit slice tid>>6),
@@ -323,12 +343,12 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                     lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
                     Hn -= zz[k] * lp[k];
                 }
-            if (!AC && U > 0) {                            // folded over the transitions of state n
-                const long long* row = sga + n * kPad;
+            if (!AC && U > 0) {                            // folded over the transitions of state c0 + tid
+                const long long* row = sga + tid * kPad;
                 long long sg = 0;
 #pragma unroll
                 for (int k = 0; k < kPad; k++) if (k < A) sg += row[k];
-                const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[n];
+                const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[tid];
 #pragma unroll
                 for (int k = 0; k < kPad; k++)
                     zz[k] = k < A ? (zz[k] * SG - (float)((double)row[k] * 0x1p-40) + cnt * (ent_coef * zz[k] * (lp[k] + Hn))) * invN
@@ -500,7 +520,7 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
     return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
-                            (value_head ? 2 * nx + kH : nx + kChunk + kUmax + 8 + 512 + 2 * (size_t)kUmax * pad));
+                            (value_head ? 2 * nx + kH : nx / 2 + kHash + kUmax + 8 + kHash + kHash / 2 + 2 * (size_t)kUmax * pad));
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
