@@ -110,6 +110,19 @@ def test_product_path_fails_loudly_without_gpu():
         QTable(**CFG_AGENT).get_action(np.array([3.0]))
     with pytest.raises(ThrlError):
         NoisyPriceState(**CFG_ENV).step([0.3, 0.3])
+    # the neural agents and the mixed-agent batch have no CPU path either
+    from th_rl_amd.agents import CAC, ActorCritic, Reinforce
+    from th_rl_amd.mixed import MixedGameBatch
+    from th_rl_amd.nn import CACBatch, ReinforceBatch
+    nn_kw = dict(states=1, actions=21, action_range=[0.2, 0.4])
+    for make in (lambda: MixedGameBatch({"agents": [dict(CFG_AGENT, name="QTable"), dict(nn_kw, name="Reinforce")],
+                                         "environment": dict(CFG_ENV)}, n_games=2),
+                 lambda: ReinforceBatch(2, actions=21), lambda: CACBatch(2),
+                 lambda: Reinforce(**nn_kw).get_action(np.array([3.0])),
+                 lambda: ActorCritic(**nn_kw).sample_action(np.array([3.0])),
+                 lambda: CAC(states=1, action_range=[0.2, 0.4]).get_action(np.array([3.0]))):
+        with pytest.raises(ThrlError):
+            make()
 
 
 def test_create_game_reference_schema(tmp_path):
