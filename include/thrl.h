@@ -12,6 +12,15 @@
  * enqueued on the caller's HIP stream (passed as void*, 0 = default stream)
  * and is asynchronous; the caller synchronises.
  *
+ * Re-entrant and thread-safe: calls on different threads / streams / devices do
+ * not share mutable state.  The only process-wide state is (i) the thread-local
+ * error string, (ii) a read-only cache of per-device figures (CU count, LDS per
+ * CU, resident waves per CU from hipDeviceProp_t), keyed by the HIP device id
+ * and filled once per device under a lock, and (iii) the tuning knob
+ * THRL_WAVE_MAX_WAVES_PER_CU, read from the environment once per process.
+ * Launch geometry and thrl_workspace_bytes() refer to the CURRENT HIP device of
+ * the calling thread (hipSetDevice / torch.cuda.device).
+ *
  * Plain C: no torch / HIP types in any signature.
  */
 #ifndef THRL_H
@@ -128,6 +137,8 @@ size_t thrl_table_stride(const thrl_cfg* cfg);
 /* element offset of agent i's table inside one game's slab */
 size_t thrl_table_offset(const thrl_cfg* cfg, int agent);
 size_t thrl_replay_mem_bytes(const thrl_cfg* cfg);
+/* scratch the episode kernels need for THIS config on the current device (payoff LUT image, per-wave
+ * log partials and transition log of the wave kernel's persistent grid); 0 on a bad config */
 size_t thrl_workspace_bytes(const thrl_cfg* cfg);
 /* which kernel THRL_KERNEL_AUTO would pick for this config (thrl_kernel) */
 int    thrl_select_kernel(const thrl_cfg* cfg, int injected);

@@ -162,6 +162,55 @@ def test_sharded_launch_equals_single_process(tmp_path):
     np.testing.assert_allclose(l2, l1, rtol=1e-12)
 
 
+def test_sharded_launch_one_game_per_rank_and_more_ranks_than_games(tmp_path):
+    """2 games over 3 requested ranks (clamped to 2, one game each) equals 2 games in one process: a
+    one-game shard keeps float32 tables and the Philox initialisation keyed by the global game id."""
+    import torch
+    from th_rl_amd import trainer
+    from th_rl_amd.launch import launch
+    cfg = _config(5, seed=23, n_games=2, print_freq=500)
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    trainer.train_one(str(tmp_path / "one"), str(tmp_path / "c.json"))
+    launch(str(tmp_path / "c.json"), str(tmp_path / "two"), gpus=3)
+    assert not (tmp_path / "two" / "shard2").exists()
+    one = torch.load(tmp_path / "one" / "batch.pt", weights_only=True)
+    s0 = torch.load(tmp_path / "two" / "shard0" / "batch.pt", weights_only=True)
+    s1 = torch.load(tmp_path / "two" / "shard1" / "batch.pt", weights_only=True)
+    assert s0["q"].dtype == torch.float32 and s1["game_offset"] == 1
+    assert torch.equal(torch.cat([s0["q"], s1["q"]]), one["q"])
+    assert torch.equal(torch.cat([s0["counter"], s1["counter"]]), one["counter"])
+    for f in ("0.npy", "1.npy", "0_counter.npy"):
+        assert open(tmp_path / "two" / f, "rb").read() == open(tmp_path / "one" / f, "rb").read(), f
+
+
+def test_two_batches_on_two_streams_equal_sequential_runs():
+    """Re-entrancy on the device side: two independent batches launched back to back on two HIP
+    streams (each with its own workspace and work counter) give the results of running them alone."""
+    import torch
+    from th_rl_amd.batched import GameBatch
+    config = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV)}
+    def fresh(seed):
+        return GameBatch(config, n_games=3000, seed=seed, kernel="wave").init_tables()
+    alone = []
+    for seed in (1, 2):
+        gb = fresh(seed)
+        gb.run(6)
+        alone.append((gb.tables_numpy(), gb.counters_numpy(), gb.states_numpy()))
+    a, b = fresh(1), fresh(2)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    keep = []
+    for _ in range(3):                                  # interleaved launches, 2 episodes each
+        with torch.cuda.stream(s1):
+            keep.append(a.run(2, sync=False))
+        with torch.cuda.stream(s2):
+            keep.append(b.run(2, sync=False))
+    torch.cuda.synchronize()
+    for gb, (q, c, st) in zip((a, b), alone):
+        assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+        assert np.array_equal(gb.states_numpy(), st)
+
+
 def test_train_one_sweep(tmp_path):
     """A gamma sweep (the reference's configs2.json value 0.35 vs example_config's 0.95) as one
     batched train_one: game g equals a plain run whose config has that gamma."""

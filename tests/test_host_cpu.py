@@ -78,6 +78,50 @@ def test_host_logic_layout_and_kernel_selection(lib):
         assert why in lib.thrl_last_error().decode(), (mod, lib.thrl_last_error())
 
 
+def test_workspace_is_sized_from_the_config(lib):
+    from th_rl_amd import _lib
+    def ws(G, **mod):
+        c = json.loads(json.dumps(CFG))
+        c["environment"].update(mod.get("env", {}))
+        cfg, _ = _lib.cfg_from_config(c, G, mod.get("q", 0))
+        return lib.thrl_workspace_bytes(ctypes.byref(cfg))
+    big, small = ws(1 << 20), ws(64)
+    # 20 resident waves on each of 256 CUs: per wave 32 x 4 log partials + 32 episodes x 2 segments x 64 packed transitions
+    assert big == 16384 + 5120 * (1024 + 32 * 2 * 64 * 4) and small == 16384 + 64 * (1024 + 32 * 2 * 64 * 4)
+    assert ws(1 << 20, env={"max_steps": 128}) == big and ws(1 << 20, env={"max_steps": 129}) > big
+    assert ws(1 << 20, q=1) == 16384                       # generic kernel: nothing kept in the workspace
+    bad, _ = _lib.cfg_from_config(CFG, 4, 0)
+    bad.n_agents = 0
+    assert lib.thrl_workspace_bytes(ctypes.byref(bad)) == 0
+
+
+def test_host_entry_points_from_two_threads(lib):
+    """Re-entrancy of the host logic (include/thrl.h): two threads hammer thrl_select_kernel /
+    thrl_workspace_bytes with different configs; every answer equals the single-threaded one and
+    each thread sees its own thrl_last_error()."""
+    import threading
+    from th_rl_amd import _lib
+    wave_cfg, _ = _lib.cfg_from_config(CFG, 1 << 16, 0)
+    c3 = json.loads(json.dumps(CFG)); c3["agents"].append(dict(CFG_AGENT)); c3["environment"]["nplayers"] = 3
+    gen_cfg, _ = _lib.cfg_from_config(c3, 1 << 16, 0)
+    want = {"wave": (lib.thrl_select_kernel(ctypes.byref(wave_cfg), 0), lib.thrl_workspace_bytes(ctypes.byref(wave_cfg))),
+            "gen": (lib.thrl_select_kernel(ctypes.byref(gen_cfg), 0), lib.thrl_workspace_bytes(ctypes.byref(gen_cfg)))}
+    assert want["wave"][0] == _lib.KERNEL_WAVE and want["gen"][0] == _lib.KERNEL_GENERIC
+    bad = []
+    def hammer(name, cfg, expect_msg):
+        for _ in range(2000):
+            k = lib.thrl_select_kernel(ctypes.byref(cfg), 0)
+            msg = lib.thrl_last_error().decode()
+            w = lib.thrl_workspace_bytes(ctypes.byref(cfg))
+            if (k, w) != want[name] or (expect_msg and expect_msg not in msg):
+                bad.append((name, k, w, msg))
+                return
+    ts = [threading.Thread(target=hammer, args=("wave", wave_cfg, None)),
+          threading.Thread(target=hammer, args=("gen", gen_cfg, "2 agents"))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not bad, bad[:2]
+
+
 def test_error_codes_never_throw(lib):
     from th_rl_amd import _lib
     cfg, _ = _lib.cfg_from_config(CFG, 4, 0)
@@ -198,6 +242,31 @@ def test_shard_range_partitions():
             assert o0 + n0 == o1
     with pytest.raises(ValueError):
         shard_range(8, 8, 8)
+
+
+def test_launch_shard_config_is_independent_of_the_shard_size():
+    """th_rl_amd.launch: a shard of ONE game must still run float32 tables initialised from Philox by
+    global game id (train_one's one-game defaults are float64 + numpy's RNG), and there are never more
+    ranks than games."""
+    from th_rl_amd.launch import effective_world, shard_training
+    cfg = dict(CFG, training={"epochs": 3, "n_games": 2, "seed": 5, "sweep": {"gamma": [0.3, 0.9]}})
+    t0, off0, n0 = shard_training(cfg, 0, 2)
+    t1, off1, n1 = shard_training(cfg, 1, 2)
+    assert (off0, n0, off1, n1) == (0, 1, 1, 1)
+    for t in (t0, t1):
+        assert t["dtype"] == "float32" and t["philox_init"] is True and t["n_games"] == 1 and t["seed"] == 5
+    assert t1["game_offset"] == 1 and t0["sweep"] == {"gamma": [0.3]} and t1["sweep"] == {"gamma": [0.9]}
+    assert effective_world(cfg, 8) == 2 and effective_world(cfg, 1) == 1
+    three = dict(CFG, training={"n_games": 3, "seed": 1, "dtype": "float64", "game_offset": 10})
+    t, off, n = shard_training(three, 1, 2)
+    assert (t["dtype"], t["game_offset"], n) == ("float64", 12, 1)
+    one = dict(CFG, training={"n_games": 1, "seed": 1})          # an unsharded single game keeps the reference defaults
+    t, off, n = shard_training(one, 0, effective_world(one, 4))
+    assert t["dtype"] == "float64" and t["philox_init"] is False
+    with pytest.raises(ValueError):
+        shard_training(cfg, 2, 3)                                 # an empty shard is a caller error
+    with pytest.raises(SystemExit):
+        shard_training(dict(CFG, training={"n_games": 4}), 0, 2)  # no shared seed
 
 
 def _free_port():

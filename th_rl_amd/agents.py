@@ -6,9 +6,11 @@ once goes through GameBatch / train_one instead.  Host-side state (`table`,
 `counter`, `epsilon`, `memory`) keeps the reference's attribute names so
 utils.load_experiment / plot_qagent style consumers keep working.
 
-Reinforce acts and trains on the device too.  ActorCritic and CAC
-are constructible so that configs naming them load, but their compute methods raise
-NotImplementedError (not built yet).
+Reinforce, ActorCritic and CAC act and train on the device too
+(thrl_nn_* / thrl_ac_* / thrl_cac_*); the torch modules only hold the parameters in the reference's
+state_dict format.  Their `reset` / `reset_value` / `reset_pi` methods are deliberately absent: in the
+reference they touch layers that do not exist (agents.py:202,207,436) and nothing calls them
+(DESIGN.md section 8).
 """
 from collections import namedtuple
 import random
@@ -83,7 +85,11 @@ class QTable:
         return rows.reshape(state.shape)
 
     def scale(self, actions):
-        return self._device_ops().scale(0, actions)
+        """agents.py:51-57; like the reference it takes a scalar index or an array of indices."""
+        if numpy.ndim(actions) == 0:
+            return self._device_ops().scale(0, actions)
+        a = numpy.asarray(actions)
+        return numpy.array([self._device_ops().scale(0, int(k)) for k in a.ravel()]).reshape(a.shape)
 
     def sample_action(self, state):
         """epsilon-greedy; the two stdlib draws are made exactly where the reference makes them."""

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "thrl_kernels.h"
 #include "thrl_wave_lut.h"
 
@@ -116,16 +118,44 @@ struct WavePlan {
     int lut_bytes, game_lds_bytes, waves_per_block, blocks_per_cu;
 };
 
-int g_num_cu = 0;
-int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cu = prop.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
+// Per-device figures the launch geometry needs.  A read-only cache keyed by the HIP device id (filled
+// once per device under a mutex; the only process-wide state besides the thread-local error string).
+// Without a visible device (the CPU-side tests of the host logic) the MI355X figures are assumed.
+struct DevInfo { int cus, lds_per_cu, waves_per_cu; };
+constexpr DevInfo kMi355x = {256, 160 * 1024, 32};
+constexpr int kMaxDevices = 64;
+
+DevInfo dev_info() {
+    static std::mutex mu;
+    static DevInfo cache[kMaxDevices];
+    static bool have[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        (void)hipGetLastError();
+        return kMi355x;
     }
-    return g_num_cu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!have[dev]) {
+        DevInfo d = kMi355x;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return kMi355x; }
+        if (prop.multiProcessorCount > 0) d.cus = prop.multiProcessorCount;       // 256; 32 per XCD partition
+        if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) d.lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+        if (prop.maxThreadsPerMultiProcessor >= 64) d.waves_per_cu = prop.maxThreadsPerMultiProcessor / 64;
+        cache[dev] = d;
+        have[dev] = true;
+    }
+    return cache[dev];
+}
+
+// THRL_WAVE_MAX_WAVES_PER_CU: tuning / diagnostic knob, read ONCE per process (not per call)
+int env_wave_cap() {
+    static std::once_flag once;
+    static int cap = 0;
+    std::call_once(once, [] {
+        if (const char* e = getenv("THRL_WAVE_MAX_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 64) cap = v; }
+    });
+    return cap;
 }
 
 // Can the fused wave kernel run this config?  (DESIGN.md "wave kernel: eligibility")
@@ -175,8 +205,9 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     p.game_lds_bytes = 2 * (p.win_rows + 2) * A * 4;
     // choose waves/block to maximise resident waves per CU (LDS-bound), block LDS <= 64 KiB
     int best_w = 0, best_total = 0, best_b = 0;
-    int cap_waves = 32;                                   // tuning/diagnostic knob
-    if (const char* e = getenv("THRL_WAVE_MAX_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) cap_waves = v; }
+    const DevInfo dv = dev_info();
+    int cap_waves = dv.waves_per_cu;
+    if (env_wave_cap() > 0 && env_wave_cap() < cap_waves) cap_waves = env_wave_cap();
     // Most resident waves wins (throughput is latency-bound and scales with them).  A block's waves
     // are dealt to the CU's 4 SIMDs in turn, so among equal totals blocks of 4k waves are preferred
     // (they load the SIMDs evenly); with games handed out dynamically an uneven split only costs the
@@ -187,7 +218,7 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     for (int w = 1; w <= 16; w++) {
         const int lds = p.lut_bytes + w * p.game_lds_bytes;
         if (lds > 65536) break;
-        int b = 163840 / (((lds + 511) / 512) * 512);
+        int b = dv.lds_per_cu / (((lds + 511) / 512) * 512);
         if (b * w > cap_waves) b = cap_waves / w;
         if (b < 1) continue;
         const int total = b * w;
@@ -207,9 +238,25 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
-constexpr size_t kMaxWaves = 256 * 32;          // at most 32 resident waves on each of 256 CUs
-constexpr size_t kTlogBytesPerWave = (size_t)kWaveMaxEpisodes * 4 * 64 * 4;   // 32 episodes x 4 segments x 64 steps
-constexpr size_t kPartialBytes = kMaxWaves * 4 * kWaveMaxEpisodes * sizeof(long long);
+
+// Workspace of the wave kernel, sized from the config and the current device:
+//   [0, kLutRegion)   payoff-LUT image (+ the launch's work counter in its last 64 bytes)
+//   partial           [total_waves][kWaveMaxEpisodes][4] fixed-point log sums
+//   tlog              [total_waves][kWaveMaxEpisodes][NSEG][64] packed transitions (visit counters)
+// total_waves = the persistent grid: resident blocks per CU x CUs, or fewer when G is small.
+struct WaveWs { int grid, total_waves; size_t partial_off, tlog_off, bytes; };
+WaveWs wave_workspace(const thrl_cfg* c, const WavePlan& p) {
+    WaveWs w;
+    w.grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
+    const int max_grid = dev_info().cus * p.blocks_per_cu;
+    if (w.grid > max_grid) w.grid = max_grid;
+    w.total_waves = w.grid * p.waves_per_block;
+    const size_t nseg = (size_t)(c->max_steps + 63) / 64;
+    w.partial_off = kLutRegion;
+    w.tlog_off = w.partial_off + align_up((size_t)w.total_waves * 4 * kWaveMaxEpisodes * sizeof(long long), 256);
+    w.bytes = w.tlog_off + align_up((size_t)w.total_waves * kWaveMaxEpisodes * nseg * 64 * sizeof(uint32_t), 256);
+    return w;
+}
 
 }  // namespace
 
@@ -236,8 +283,10 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
     return align_up(n * 2, 256) * 3 + align_up(n * 8, 256) * 2;
 }
 size_t thrl_workspace_bytes(const thrl_cfg* c) {
-    (void)c;
-    return kLutRegion + kPartialBytes + kMaxWaves * kTlogBytesPerWave;
+    if (validate(c) != THRL_OK) return 0;
+    const WavePlan p = plan_wave(c, nullptr, false);
+    if (!p.ok) return kLutRegion;                  // the generic kernel keeps nothing there
+    return wave_workspace(c, p).bytes;
 }
 int thrl_select_kernel(const thrl_cfg* c, int injected) {
     if (validate(c) != THRL_OK) return THRL_ERR_BAD_CONFIG;
@@ -342,7 +391,8 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     a.q = (float*)b->q; a.counter = b->counter; a.state = b->state;
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut_ns = lut;
-    a.partial = (long long*)((char*)b->workspace + kLutRegion);
+    const WaveWs ws = wave_workspace(c, p);
+    a.partial = (long long*)((char*)b->workspace + ws.partial_off);
     {   // fixed-point scales of the log sums: 2^s with G * (bound of one game's episode mean) * 2^s <= 2^62
         double hi = 0.0;
         for (int i = 0; i < 2; i++) hi = fmax(hi, fmax(fabs(c->act_lo[i]), fabs(c->act_hi[i])));
@@ -355,7 +405,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
             a.log_scale[k] = ldexp(1.0, sh);
         }
     }
-    a.tlog = (uint32_t*)((char*)b->workspace + kLutRegion + kPartialBytes);
+    a.tlog = (uint32_t*)((char*)b->workspace + ws.tlog_off);
     a.next_game = (int32_t*)((char*)b->workspace + kLutRegion - 64);       // the LUT image is < 16 KiB - 64
     a.seed = run->seed; a.game_offset = run->game_offset;
     a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
@@ -366,11 +416,8 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
         return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it sizes the row window)");
 
     const int block = p.waves_per_block * 64;
-    int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
-    const int max_grid = num_cu() * p.blocks_per_cu;      // persistent grid; games are handed out by a work counter
-    if (grid > max_grid) grid = max_grid;
-    a.total_waves = grid * p.waves_per_block;
-    if ((size_t)a.total_waves > kMaxWaves) return fail(THRL_ERR_WORKSPACE, "too many waves for workspace");
+    const int grid = ws.grid;                             // persistent grid; games are handed out by a work counter
+    a.total_waves = ws.total_waves;
     const size_t lds = (size_t)p.lut_bytes + (size_t)p.waves_per_block * p.game_lds_bytes;
 
     int e = launch_wave_lut(a, lut, s);

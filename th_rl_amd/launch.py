@@ -27,26 +27,49 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, config, out, devices_available):
-    import torch
-    import torch.distributed as dist
-    from th_rl_amd import trainer
-    from th_rl_amd.sharding import aggregate_logs, shard_range
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+def shard_training(config, rank, world):
+    """The `training` block rank `rank` of `world` runs: its contiguous block of global game ids, with
+    everything that must not depend on the shard size pinned to what the unsharded run would use --
+    the table dtype (train_one's default is float64 for ONE game, float32 otherwise) and the Philox
+    initialisation keyed by (seed, global game id) (train_one's one-game default draws the tables
+    from numpy's global RNG instead).  Pure host logic (no GPU): tests/test_host_cpu.py."""
+    from th_rl_amd.sharding import shard_range
     training = dict(config.get("training", {}))
     total = int(training.get("n_games", world))
+    if training.get("seed") is None:
+        raise SystemExit("th_rl_amd.launch needs an explicit training.seed (all shards must share it)")
     offset, n_local = shard_range(total, rank, world)
+    if n_local < 1:
+        raise ValueError("rank %d of %d has no games (n_games=%d): launch() clamps the world first" % (rank, world, total))
+    training.setdefault("dtype", None)
+    if not training["dtype"]:
+        training["dtype"] = "float64" if total == 1 else "float32"
     training.update(n_games=n_local, game_offset=int(training.get("game_offset", 0)) + offset,
-                    device="cuda:%d" % (rank % max(1, devices_available)), checkpoint=True)
+                    philox_init=(total > 1) or bool(training.get("philox_init", False)), checkpoint=True)
     sweep = training.get("sweep")
     if sweep:        # slice the per-game arrays to this shard
         def cut(v):
             a = numpy.asarray(v)
             return a[..., offset:offset + n_local].tolist()
         training["sweep"] = {k: cut(v) for k, v in sweep.items()}
-    if training.get("seed") is None:
-        raise SystemExit("th_rl_amd.launch needs an explicit training.seed (all shards must share it)")
+    return training, offset, n_local
+
+
+def effective_world(config, gpus):
+    """Never more ranks than games: an empty shard has nothing to run."""
+    total = int(config.get("training", {}).get("n_games", gpus))
+    return max(1, min(int(gpus), total))
+
+
+def _worker(rank, world, port, config, out, devices_available):
+    import torch
+    import torch.distributed as dist
+    from th_rl_amd import trainer
+    from th_rl_amd.sharding import aggregate_logs
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    training, offset, n_local = shard_training(config, rank, world)
+    training["device"] = "cuda:%d" % (rank % max(1, devices_available))
     shard_cfg = dict(config, training=training)
     shard_dir = os.path.join(out, "shard%d" % rank)
     os.makedirs(shard_dir, exist_ok=True)
@@ -82,7 +105,7 @@ def launch(configpath, out, gpus=None):
     if avail < 1:
         from th_rl_amd._lib import ThrlError
         raise ThrlError("th_rl_amd.launch: no GPU visible; there is no CPU fallback")
-    world = int(gpus or avail)
+    world = effective_world(config, int(gpus or avail))     # a shard needs at least one game
     os.makedirs(out, exist_ok=True)
     port = _free_port()
     mp.spawn(_worker, args=(world, port, config, out, avail), nprocs=world, join=True)

@@ -1,16 +1,20 @@
-"""MixedGameBatch: G games whose agents may be any mix of QTable and Reinforce (the pairing the
-reference's own example configs use), stepped in lockstep with the UNFUSED device operators of
-libthrl_hip.so -- the same call sequence as trainer.train_one's loop (th_rl/trainer.py:46-70),
-one launch per reference call, applied to all games at once:
+"""MixedGameBatch: G games whose agents may be any mix of QTable, Reinforce, ActorCritic and CAC
+(the reference's example configs pair a QTable with a Reinforce agent), stepped in lockstep on the
+device.  Two equivalent ways to run trainer.train_one's loop (th_rl/trainer.py:46-70):
 
-    thrl_op_draws -> thrl_op_sample_action | thrl_nn_act -> thrl_op_scale -> thrl_op_env_step
-    -> (append) -> per episode thrl_op_td_update | thrl_nn_reinforce_train
+  * fused (default): thrl_mixed_episodes -- one wavefront per game plays all episodes between two
+    network updates in ONE launch (tables in LDS, networks in registers), then the batched update
+    kernels (thrl_nn_reinforce_train / thrl_ac_train / thrl_cac_train) run when len(memory) >=
+    min_memory;
+  * unfused (`run(fused=False)`): the reference's call sequence, one launch per reference call,
+        thrl_op_draws -> thrl_op_sample_action | thrl_nn_act -> thrl_op_scale -> thrl_op_env_step
+        -> (append) -> per episode thrl_op_td_update | train
+    kept as the reference-shaped checker of the fused kernel (bit-identical results, tested).
 
-All-QTable configs should use GameBatch (fused kernels, ~20x faster); this path exists so that
-configs with neural agents run on the device too.  The random streams are the ones the fused
-kernels use, so an all-QTable game gives bit-identical tables on both paths.
-torch is used for device memory and for three one-line float64 element-wise expressions
-(Reinforce.scale and the two log accumulations).
+The random streams are the ones GameBatch's kernels use, so an all-QTable game gives bit-identical
+tables on all paths.  Per-game hyper-parameter sweeps: `sweep=` (see set_sweep).
+torch is used for device memory and for three one-line float64 element-wise expressions of the
+unfused loop (Reinforce.scale and the two log accumulations).
 """
 import ctypes
 
@@ -84,9 +88,22 @@ class MixedGameBatch:
                              reward=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
                              nprice=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device))
                         for i, n in enumerate(self.buf_len)]
+        # a network update replays the whole buffer: T * ceil(min_memory / T) transitions (the check runs at
+        # episode ends only).  The update kernels keep the batch in LDS, so reject a config that cannot
+        # train HERE, not at the first update half-way through a run.
+        for i, p in self.nn_cfg.items():
+            if self.cap[i] < self.min_memory[i] or self.min_memory[i] <= 0:
+                continue                      # never trains (or trains on every call with whatever is there)
+            n_train = min(self.cap[i], self.T * -(-self.min_memory[i] // self.T))
+            limit = 5600 if self.kinds[i] == "CAC" else 1400          # THRL_NN_MAX_TRANSITIONS / CAC's LDS bound
+            if n_train > limit:
+                raise ThrlError("%s agent %d would train on %d transitions per update (min_memory=%d, max_steps=%d); "
+                                "the device update kernel takes at most %d" % (self.kinds[i], i, n_train,
+                                                                                self.min_memory[i], self.T, limit))
         self.count = [0] * self.N            # appends since the last empty()
         self.episode = 0
         self.initialized = False
+        self._fused_launched = False         # True once a fused launch has advanced the state
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -256,12 +273,15 @@ class MixedGameBatch:
         (default): fused unless the library reports the configuration as unsupported by that kernel
         (more than two Reinforce / ActorCritic agents, tables beyond 64 KiB of LDS per game, > 64 actions)."""
         if fused is None:
+            first = self.episode
             try:
                 return self._run_fused(int(n_episodes), per_game_logs)
             except ThrlError as e:
-                if e.code != _lib.ERR_UNSUPPORTED:
+                # fall back only if the episode kernel itself refused the configuration, i.e. before any
+                # launch changed tables / buffers / episode index
+                if e.code != _lib.ERR_UNSUPPORTED or self.episode != first or self._fused_launched:
                     raise
-                return self._run_unfused(int(n_episodes))      # nothing was launched: state is untouched
+                return self._run_unfused(int(n_episodes))
         if fused:
             return self._run_fused(int(n_episodes), per_game_logs)
         return self._run_unfused(int(n_episodes))
@@ -311,6 +331,7 @@ class MixedGameBatch:
                                                       self._p(self.counter), self._p(self.state), ctypes.byref(r),
                                                       self._p(rlog[base:]), self._p(alog[base:]), self._stream()),
                            "thrl_mixed_episodes")
+                self._fused_launched = True
                 rmean[done:done + k] = rlog[base:base + k].mean(dim=2)
                 amean[done:done + k] = alog[base:base + k].mean(dim=2)
                 self.eps = [r.eps[i] for i in range(N)] + self.eps[N:]

@@ -7,7 +7,10 @@ kernels).  The JSON schema is the reference's; the optional extra keys in the
 
     "training": {"epochs": .., "print_freq": ..,
                  "n_games": 1,        # games trained in lockstep (independent replicas)
-                 "seed": null,        # Philox seed (null: drawn from numpy's global RNG)
+                 "seed": null,        # Philox seed (null: fresh OS entropy; numpy's global stream is left exactly
+                                      # as the reference's train_one leaves it)
+                 "philox_init": false, # true: tables / initial state from Philox keyed by (seed, global game id)
+                                      # even for ONE game (what a 1-game shard of a sharded run needs)
                  "dtype": null,       # "float64" | "float32" (default f64 for 1 game, f32 otherwise)
                  "device": "cuda:0", "game_offset": 0, "kernel": "auto",
                  "resume": null,     # path of a batch.pt written by an earlier run: continue it
@@ -78,7 +81,9 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     n_games = int(training.get("n_games", 1))
     seed = training.get("seed", None)
     if seed is None:
-        seed = int(numpy.random.randint(0, 2 ** 31 - 1))
+        # independent of numpy's global stream: under numpy.random.seed(s) the constructors above and
+        # environment.reset() below then draw exactly the values the reference's train_one draws
+        seed = int(numpy.random.SeedSequence().entropy % (2 ** 31 - 1))
     dtype = training.get("dtype", None) or ("float64" if n_games == 1 else "float32")
     names = [a["name"] for a in config["agents"]]
 
@@ -103,7 +108,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
                                seed=seed, game_offset=int(training.get("game_offset", 0)))
     if resume:
         batch.load(resume)                              # tables, counters, state, epsilon, episode index
-    elif n_games == 1:
+    elif n_games == 1 and not training.get("philox_init", False):
         state = environment.reset()                     # drawn once, as trainer.py:45
         if all_tabular and not small_tabular:
             batch.set_tables(numpy.concatenate([a.table.ravel() for a in agents])[None, :], [float(state[0])])
