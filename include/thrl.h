@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define THRL_ABI_VERSION 1
+#define THRL_ABI_VERSION 2          /* 2: per-game sweeps in thrl_qtable_init, thrl_mixed and the *_train entry points */
 #define THRL_MAXA 8          /* max agents per game (reference configs use 2) */
 #define THRL_MAX_EPISODES_PER_LAUNCH 32
 
@@ -105,7 +105,7 @@ typedef struct {
     size_t   workspace_bytes;
     /* Per-game hyper-parameter sweeps (optional; NULL = thrl_cfg's scalar for every game): the
      * reference sweeps configs x runs one process at a time (main.py:13-21); here a sweep is a
-     * per-game array.  Device, layout [N][G] (agent-major); fused wave kernel only. */
+     * per-game array.  Device, layout [N][G] (agent-major); honoured by both episode kernels. */
     const double* sweep_gamma;       /* QTable gamma  (agents.py:30)                     */
     const double* sweep_alpha;       /* QTable alpha  (agents.py:31)                     */
     const double* sweep_eps_end;     /* agents.py:37                                     */
@@ -147,10 +147,11 @@ int    thrl_select_kernel(const thrl_cfg* cfg, int injected);
  * Replaces QTable.__init__ table/counter init (agents.py:29,45) and
  * NoisyPriceState.reset() (environments.py:50-53, called once at trainer.py:45)
  * for all G games: q = 12.5/(1-gamma_i) + N(0,1), counter = 0, state ~ U(0,a),
- * from Philox4x32-10 keyed by (seed, global game id).
+ * from Philox4x32-10 keyed by (seed, global game id).  sweep_gamma: device [N][G] per-game gamma
+ * (the table offset of a config sweep) or NULL for thrl_cfg.gamma.
  */
 int thrl_qtable_init(const thrl_cfg* cfg, void* q, int32_t* counter, double* state,
-                     uint64_t seed, uint64_t game_offset, void* stream);
+                     uint64_t seed, uint64_t game_offset, const double* sweep_gamma, void* stream);
 
 /*
  * THE hot path: replaces the body of trainer.train_one's loop (trainer.py:46-70)
@@ -227,10 +228,12 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
 /* Reinforce.train_net's update (agents.py:171-193) for G games on n replayed transitions each:
  * discounted returns, z-score (unbiased std), policy-gradient + entropy loss, gradient-norm clip
  * at 1.0, one Adam step (lr, betas 0.9/0.999, eps 1e-8).  step = Adam step count BEFORE the call.
- * grad_out [G][P] (optional) receives the clipped gradient. */
+ * sweep_gamma / sweep_entropy: device [G] per-game values (a config sweep as one batch) or NULL for
+ * the scalars.  grad_out [G][P] (optional) receives the clipped gradient. */
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
                             int32_t step, int32_t n, const double* price, const int32_t* action,
                             const double* reward, double gamma, double entropy_coef, double lr,
+                            const double* sweep_gamma, const double* sweep_entropy,
                             float* grad_out, void* stream);
 /*
  * `ActorCritic` (agents.py:222-330): Reinforce's network plus a value head fc_v (256 -> 1, bias
@@ -251,7 +254,7 @@ int thrl_ac_act(int n_games, int n_actions, const float* params, const double* p
 int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
                   int32_t step, int32_t n, const double* price, const int32_t* action,
                   const double* reward, const double* next_price, double gamma, double entropy_coef,
-                  double lr, float* grad_out, void* stream);
+                  double lr, const double* sweep_gamma, const double* sweep_entropy, float* grad_out, void* stream);
 /*
  * `CAC`, the continuous actor-critic (agents.py:333-442): fc1 (1 -> 256) and three 256 -> 1 heads,
  * mu = 4*tanh(fc_mu h), std = softplus(fc_std h), v = fc_v h.  THRL_CAC_PARAMS floats per game:
@@ -273,7 +276,8 @@ int thrl_cac_act(int n_games, const float* params, const double* price, const do
                  float* action_out, float* mu_out, float* std_out, float* v_out, void* stream);
 int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
                    const double* price, const float* action, const double* reward, const double* next_price,
-                   double gamma, double entropy_coef, double lr, float* grad_out, void* stream);
+                   double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
+                   float* grad_out, void* stream);
 /*
  * Fused episodes for games whose agents are any mix of QTable and Reinforce (the pairing of the
  * reference's example configs): trainer.train_one's loop (trainer.py:46-70) with QTable.train_net
@@ -292,6 +296,15 @@ typedef struct {
     int32_t  buf_len[THRL_MAXA];
     int32_t  min_memory[THRL_MAXA];
     int32_t  count[THRL_MAXA];           /* in/out: appends since the last memory.empty()    */
+    /* per-game sweeps of the QTable agents and the env, as in thrl_buffers: device [N][G] (noise_prob
+     * [G]) or NULL.  Rows of neural agents are ignored here (their gamma / entropy sweep goes to the
+     * *_train calls). */
+    const double* sweep_gamma;
+    const double* sweep_alpha;
+    const double* sweep_eps_end;
+    const double* sweep_eps_step;
+    double*       sweep_eps;             /* in/out: current epsilon per (agent, game)        */
+    const double* sweep_noise_prob;
 } thrl_mixed;
 int thrl_mixed_episodes(const thrl_cfg* cfg, thrl_mixed* mx, void* q, int32_t* counter, double* state,
                         thrl_run* run, double* game_reward_log, double* game_action_log, void* stream);

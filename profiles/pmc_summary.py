@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Mean per-dispatch value of every counter collected for one kernel in gpurun_out/<tag>_pmc_*.
+
+    python profiles/pmc_summary.py it1 [--kernel k_wave_episodes] [--out profiles/r02_x.csv]
+"""
+import argparse, collections, csv, glob, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+def collect(tag, kernel):
+    counters = collections.OrderedDict(); geom = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_pmc_*", "*", "*_counter_collection.csv"))):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                geom = dict(grid=int(r["Grid_Size"]), workgroup=int(r["Workgroup_Size"]), lds=int(r["LDS_Block_Size"]),
+                            vgpr=int(r["VGPR_Count"]), sgpr=int(r["SGPR_Count"]), scratch=int(r["Scratch_Size"]))
+        for k, v in per.items():
+            counters[k] = (sum(v) / len(v), min(v), max(v), len(v))
+    return counters, geom
+
+def stats(tag, kernel):
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "*", "*_kernel_stats.csv"))):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Name"]:
+                return dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), min_ns=float(r["MinNs"]), max_ns=float(r["MaxNs"]))
+    return None
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("tag"); ap.add_argument("--kernel", default="k_wave_episodes"); ap.add_argument("--out")
+    a = ap.parse_args()
+    c, g = collect(a.tag, a.kernel)
+    st = stats(a.tag, a.kernel)
+    lines = ["counter,mean_per_dispatch,min,max,dispatches"] + ["%s,%.6g,%.6g,%.6g,%d" % ((k,) + v) for k, v in c.items()]
+    print("\n".join(lines)); print("geometry", g); print("kernel stats", st)
+    if a.out:
+        open(a.out, "w").write("\n".join(lines) + "\n")

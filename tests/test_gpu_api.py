@@ -227,13 +227,12 @@ def test_train_one_sweep(tmp_path):
         c2 = _config(4)
         for a in c2["agents"]:
             a["gamma"] = gamma
-        # the initial tables depend on gamma only through QTable's 12.5/(1-gamma) offset: compare a run
-        # started from the sweep run's own initial tables
-        init = GameBatch({"agents": cfg["agents"], "environment": cfg["environment"]}, n_games=80, seed=9).init_tables()
-        ref = GameBatch(c2, n_games=80, seed=9)
-        ref.set_tables(init.tables_numpy(), init.states_numpy())
+        # game g of the sweep IS the game a plain run of that config trains: same Philox key, and its
+        # initial table starts at that config's 12.5/(1-gamma) (agents.py:29)
+        ref = GameBatch(c2, n_games=80, seed=9).init_tables()
         ref.run(4)
         assert np.array_equal(ref.tables_numpy()[sl], b["q"].numpy()[sl])
+        assert np.array_equal(ref.counters_numpy()[sl], b["counter"].numpy()[sl])
 
 
 def test_protocol_env_step_matches_reference_grid():

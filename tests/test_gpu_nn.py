@@ -608,3 +608,45 @@ def test_reinforce_update_state_dedupe_and_plain_path(distinct):
         ow, om, ov, os_, og = NN.train_net(w0[k], np.zeros(rb.P, np.float32), np.zeros(rb.P, np.float32), 0, 21,
                                            price[:, k], action[:, k], reward[:, k], 0.97, 0.01)
         np.testing.assert_allclose(outs[0][0][k], og, rtol=2e-4, atol=2e-6)
+
+
+def test_example_config_and_configs2_as_one_sweep_equal_two_separate_runs(tmp_path):
+    """the reference's research loop is configs x runs, one process each (main.py:13-21), and
+    its two shipped configs -- example_config.json and configs2.json, both QTable vs Reinforce -- differ
+    in the QTable's gamma / alpha / epsilon and the Reinforce gamma.  Here they run as ONE batch with
+    per-game arrays, and every game is bit for bit the game its own config trains alone (tables,
+    counters, env state, network parameters and Adam state after two updates, per-game logs)."""
+    import json
+    import torch
+    from th_rl_amd import trainer
+    from th_rl_amd.mixed import MixedGameBatch
+    ex = {"agents": [dict(Q_AGENT), dict(R_AGENT)], "environment": dict(ENV)}                       # example_config.json
+    c2 = {"agents": [dict(Q_AGENT, gamma=0.35, alpha=0.5, epsilon=0.8), dict(R_AGENT, gamma=0.35)],
+          "environment": dict(ENV)}                                                                    # configs2.json
+    assert (ex["agents"][0]["gamma"], ex["agents"][1]["gamma"]) == (0.95, 0.995)
+    Gh, E = 6, 25
+    sweep = {"gamma": [[0.95] * Gh + [0.35] * Gh, [0.995] * Gh + [0.35] * Gh],
+             "alpha": [[0.1] * Gh + [0.5] * Gh, [0.0] * (2 * Gh)],
+             "eps": [[0.5] * Gh + [0.8] * Gh, [0.0] * (2 * Gh)]}
+    one = MixedGameBatch(ex, n_games=2 * Gh, seed=3, sweep=sweep).init_tables()
+    out = one.run(E)
+    assert out["kernel"] == "mixed-fused" and one.nn[1].step == 2
+    for cfg, off in ((ex, 0), (c2, Gh)):
+        alone = MixedGameBatch(cfg, n_games=Gh, seed=3, game_offset=off).init_tables()
+        oa = alone.run(E)
+        sl = slice(off, off + Gh)
+        assert np.array_equal(one.tables_numpy()[sl], alone.tables_numpy())
+        assert np.array_equal(one.counters_numpy()[sl], alone.counters_numpy())
+        assert np.array_equal(one.states_numpy()[sl], alone.states_numpy())
+        for name in ("params", "adam_m", "adam_v"):
+            assert torch.equal(getattr(one.nn[1], name)[sl], getattr(alone.nn[1], name)), name
+        assert np.array_equal(out["game_reward_log"][:, :, sl], oa["game_reward_log"])
+        assert np.array_equal(one.sweep["eps"][0, sl].cpu().numpy(), np.full(Gh, alone.eps[0]))
+    # the same sweep through train_one's JSON key
+    cfg = dict(ex, training={"epochs": 12, "print_freq": 500, "n_games": 2 * Gh, "seed": 3, "sweep": sweep})
+    (tmp_path / "sweep.json").write_text(json.dumps(cfg))
+    trainer.train_one(str(tmp_path / "run"), str(tmp_path / "sweep.json"))
+    b = torch.load(tmp_path / "run" / "batch.pt", weights_only=True)
+    ref = MixedGameBatch(ex, n_games=2 * Gh, seed=3, sweep=sweep).init_tables(); ref.run(12)
+    assert torch.equal(b["q"], ref.q.cpu()) and torch.equal(b["nn"][1]["params"], ref.nn[1].params.cpu())
+    assert torch.equal(b["sweep"]["gamma"], ref.sweep["gamma"].cpu())

@@ -65,6 +65,62 @@ def test_generic_f64_injected_matches_reference_golden(path):
     np.testing.assert_allclose(out["reward_log"], d["rewards_log"], rtol=1e-14)
 
 
+def _wave_eligible(path):
+    d = np.load(path)
+    c = json.loads(str(d["config_json"]))
+    ag, T = c["agents"], c["environment"]["max_steps"]
+    same = all(ag[0].get(k) == ag[1].get(k) for k in ("states", "actions", "max_state")) if len(ag) == 2 else False
+    return (len(ag) == 2 and same and ag[0]["actions"] <= 32 and T <= 256
+            and all(a.get("min_memory", 100) <= T <= a.get("capacity", 500) for a in ag))
+
+
+@pytest.mark.parametrize("path", [p for p in _traj_files() if _wave_eligible(p)], ids=os.path.basename)
+def test_wave_f64_injected_matches_reference_golden(path):
+    """The reference's own numerics (float64 tables) on the LDS-resident one-wavefront-per-game kernel:
+    the reference's recorded draws in => the reference's tables / counters / epsilon / state out, bit
+    for bit; its logs to 1e-12 (the kernel sums an episode's rewards before dividing by T)."""
+    d = np.load(path)
+    config = json.loads(str(d["config_json"]))
+    E, T, N = d["u"].shape
+    gb = _batch(config, 1, dtype="float64", kernel="wave")
+    gb.set_tables(d["init_tables"][None, :], [float(d["state0"])])
+    inj = dict(u=d["u"][:, :, :, None], choice=d["choice"][:, :, :, None])
+    if gb.cfg.noise_prob > 0:
+        inj.update(noise_u=d["noise_u"][:, :, None], noise_a=np.nan_to_num(d["noise_a"][:, :, None]))
+    out = gb.run(E, inj=inj)
+    assert out["kernel"] == "wave"
+    assert np.array_equal(gb.tables_numpy()[0], d["final_tables"])
+    assert np.array_equal(gb.counters_numpy()[0].astype(np.float64), d["final_counters"])
+    assert np.array_equal(np.array(gb.eps[:N]), d["eps"][-1])
+    assert gb.states_numpy()[0] == d["states"][-1, -1]
+    np.testing.assert_allclose(out["reward_log"], d["rewards_log"], rtol=1e-12)
+    np.testing.assert_allclose(out["action_log"], d["actions_log"], rtol=1e-12)
+
+
+def test_wave_f64_four_reference_runs_and_generic_kernel_at_size():
+    """float64 wave kernel: four different reference runs as one batch of four games (exact), and at
+    20,000 games it equals the float64 generic kernel bit for bit (Philox draws, 3 + 2 episodes)."""
+    ds = [np.load(os.path.join(GOLDEN, "g4_cfg_seed%d_e12.npz" % s)) for s in range(4)]
+    config = json.loads(str(ds[0]["config_json"]))
+    gb = _batch(config, 4, dtype="float64", kernel="wave")
+    gb.set_tables(np.stack([d["init_tables"] for d in ds]), [float(d["state0"]) for d in ds])
+    inj = dict(u=np.stack([d["u"] for d in ds], axis=-1), choice=np.stack([d["choice"] for d in ds], axis=-1))
+    out = gb.run(12, inj=inj)
+    assert out["kernel"] == "wave"
+    for g, d in enumerate(ds):
+        assert np.array_equal(gb.tables_numpy()[g], d["final_tables"])
+        assert np.array_equal(gb.counters_numpy()[g].astype(np.float64), d["final_counters"])
+    np.testing.assert_allclose(out["reward_log"], np.mean([d["rewards_log"] for d in ds], axis=0), rtol=1e-12)
+    G = 20000
+    a = _batch(CFG, G, dtype="float64", kernel="wave", seed=5).init_tables()
+    b = _batch(CFG, G, dtype="float64", kernel="generic", seed=5).init_tables()
+    ra = a.run(3); a.run(2); rb = b.run(5)
+    assert ra["kernel"] == "wave" and rb["kernel"] == "generic"
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy()) and np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy())
+    np.testing.assert_allclose(ra["reward_log"], rb["reward_log"][:3], rtol=1e-12)
+
+
 def test_generic_f64_injected_four_games_at_once():
     """Four different reference runs stepped in lockstep as one batch (G=4)."""
     ds = [np.load(os.path.join(GOLDEN, "g4_cfg_seed%d_e12.npz" % s)) for s in range(4)]
@@ -288,14 +344,16 @@ def _shape_config(T, A=21, states=100, rng=(0.2, 0.4), noise=0.0, cap=500):
     ("states16", _shape_config(30, A=4, states=16, rng=(0.0, 1.0)), 50, 6),   # QTable ctor defaults grid
     ("one_game", _shape_config(100), 1, 3),
 ])
-def test_wave_shapes_vs_oracle(label, config, G, E):
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_wave_shapes_vs_oracle(label, config, G, E, dtype):
     """Every template variant of the wave kernel (episode length 1..256 -> 1-4 step segments,
-    1-2 row segments, 2..32 actions, noise) against the oracle, bit for bit."""
-    gb = _batch(config, G, dtype="float32", kernel="wave", seed=12).init_tables()
+    1-2 row segments, 2..32 actions = 1-4 row reads per lane in the replay passes, noise; float32 and
+    float64 tables) against the oracle in the same dtype, bit for bit."""
+    gb = _batch(config, G, dtype=dtype, kernel="wave", seed=12).init_tables()
     q0, s0 = gb.tables_numpy(), gb.states_numpy()
     out = gb.run(E)
     assert out["kernel"] == "wave"
-    q, c, s, eps, mem, oo = _oracle_run(config, G, 0, q0, s0, E, seed=12)
+    q, c, s, eps, mem, oo = _oracle_run(config, G, 1 if dtype == "float64" else 0, q0, s0, E, seed=12)
     assert np.array_equal(gb.counters_numpy(), c)
     assert np.array_equal(gb.states_numpy(), s)
     assert np.array_equal(gb.tables_numpy(), q)
@@ -349,10 +407,42 @@ def test_per_game_sweeps_vs_oracle():
                         eps_step=np.full(33, 0.9995)))
     same.init_tables(); same.run(4)
     assert np.array_equal(plain.tables_numpy(), same.tables_numpy())
-    from th_rl_amd._lib import ThrlError
-    gen = _batch(CFG, 8, kernel="generic", seed=2); gen.set_sweep(dict(gamma=np.full(8, 0.9))); gen.init_tables()
-    with pytest.raises(ThrlError, match="wave kernel only"):
-        gen.run(1)
+    # the generic kernel takes the same arrays and gives the same games
+    gen = _batch(config, G, dtype="float32", kernel="generic", seed=21)
+    gen.set_sweep(sweep); gen.set_tables(q0, s0)
+    og = gen.run(E); gen.run(3)
+    assert og["kernel"] == "generic"
+    assert np.array_equal(gen.tables_numpy(), q) and np.array_equal(gen.counters_numpy(), c)
+    assert np.array_equal(gen.sweep["eps"].cpu().numpy(), osw["eps"])
+
+
+def test_generic_kernel_sweeps_vs_oracle():
+    """Per-game sweeps on the generic kernel (configs the wave kernel cannot take: 3 players, buffers
+    that span episodes; float64 and float32), against the oracle given the same arrays, bit for bit;
+    a gamma sweep also moves the initial table offset 12.5/(1-gamma) per game."""
+    rs = np.random.RandomState(3)
+    for config, dtype in ((THREE, "float64"), (BUFFER, "float32")):
+        G, E = 23, 6
+        N = len(config["agents"])
+        sweep = dict(gamma=rs.choice([0.35, 0.9, 0.95], (N, G)), alpha=rs.choice([0.05, 0.1, 0.5], (N, G)),
+                     eps=rs.uniform(0.1, 0.9, (N, G)), eps_end=np.full((N, G), 0.01), eps_step=rs.choice([0.9, 0.999], (N, G)))
+        gb = _batch(config, G, dtype=dtype, kernel="generic", seed=31)
+        gb.set_sweep(sweep); gb.init_tables()
+        q0, s0 = gb.tables_numpy(), gb.states_numpy()
+        plain = _batch(config, G, dtype=dtype, kernel="generic", seed=31).init_tables()
+        off = 12.5 / (1 - sweep["gamma"][0]) - 12.5 / (1 - config["agents"][0]["gamma"])     # agent 0's block moves by this
+        rows = (config["agents"][0]["states"] + 1) * config["agents"][0]["actions"]
+        np.testing.assert_allclose(q0[:, :rows] - plain.tables_numpy()[:, :rows], np.repeat(off[:, None], rows, 1),
+                                   rtol=0, atol=1e-3 if dtype == "float32" else 1e-9)
+        out = gb.run(E)
+        assert out["kernel"] == "generic"
+        cfg, eps0 = O.cfg_from_config(config, n_games=G, q_dtype=1 if dtype == "float64" else 0)
+        q, st, cn = q0.copy(), s0.copy(), np.zeros(q0.shape, np.int32)
+        osw = {k: np.ascontiguousarray(np.asarray(v, np.float64)) for k, v in sweep.items()}
+        O.episodes(cfg, q, cn, st, eps0, O.Memory(cfg), E, seed=31, sweep=osw)
+        assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), cn)
+        assert np.array_equal(gb.states_numpy(), st)
+        assert np.array_equal(gb.sweep["eps"].cpu().numpy(), osw["eps"])
 
 
 def test_learning_outcome_matches_reference_statistics():
@@ -392,8 +482,9 @@ def test_wave_forced_on_unsupported_config_fails_loudly():
     gb = _batch(BUFFER, 8, dtype="float32", kernel="wave").init_tables()
     with pytest.raises(ThrlError, match="wave kernel cannot run"):
         gb.run(1)
-    with pytest.raises(ThrlError):
-        _batch(CFG, 8, dtype="float64", kernel="wave").init_tables().run(1)
+    three = {"agents": [dict(CFG_AGENT)] * 3, "environment": dict(CFG_ENV, nplayers=3)}
+    with pytest.raises(ThrlError, match="2 agents"):
+        _batch(three, 8, dtype="float64", kernel="wave").init_tables().run(1)
 
 
 def test_full_size_properties_65536_games():

@@ -37,19 +37,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared and set(declared) == set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.thrl_version() == 1
+    assert lib.thrl_version() == 2
 
 
 def test_struct_layout_matches_header(lib):
     """ctypes mirrors of thrl_cfg / thrl_buffers / thrl_run have the C sizes."""
     import subprocess, tempfile
     from th_rl_amd import _lib
-    src = '#include <stdio.h>\n#include "thrl.h"\nint main(){printf("%zu %zu %zu\\n",sizeof(thrl_cfg),sizeof(thrl_buffers),sizeof(thrl_run));return 0;}\n'
+    src = '#include <stdio.h>\n#include "thrl.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(thrl_cfg),sizeof(thrl_buffers),sizeof(thrl_run),sizeof(thrl_mixed));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "s")]).split()))
-    assert sizes == [ctypes.sizeof(_lib.Cfg), ctypes.sizeof(_lib.Buffers), ctypes.sizeof(_lib.Run)]
+    assert sizes == [ctypes.sizeof(_lib.Cfg), ctypes.sizeof(_lib.Buffers), ctypes.sizeof(_lib.Run), ctypes.sizeof(_lib.Mixed)]
 
 
 def test_host_logic_layout_and_kernel_selection(lib):
@@ -66,7 +66,9 @@ def test_host_logic_layout_and_kernel_selection(lib):
     cn = json.loads(json.dumps(CFG)); cn["environment"]["noise_prob"] = 0.05; cn["agents"][0]["alpha"] = 0.5
     cfgn, _ = _lib.cfg_from_config(cn, 64, 0)
     assert lib.thrl_select_kernel(ctypes.byref(cfgn), 0) == _lib.KERNEL_WAVE       # noise + per-agent alpha
-    for mod, why in [(dict(q=1), "float32"), (dict(T=30), "min_memory"),
+    cfg64, _ = _lib.cfg_from_config(CFG, 1 << 20, 1)
+    assert lib.thrl_select_kernel(ctypes.byref(cfg64), 0) == _lib.KERNEL_WAVE       # float64 tables: same kernel, QT = double
+    for mod, why in [(dict(T=30), "min_memory"),
                      (dict(nag=3), "2 agents"), (dict(cap=64), "capacity")]:
         c = json.loads(json.dumps(CFG))
         if "noise" in mod: c["environment"]["noise_prob"] = mod["noise"]
@@ -89,7 +91,11 @@ def test_workspace_is_sized_from_the_config(lib):
     # 20 resident waves on each of 256 CUs: per wave 32 x 4 log partials + 32 episodes x 2 segments x 64 packed transitions
     assert big == 16384 + 5120 * (1024 + 32 * 2 * 64 * 4) and small == 16384 + 64 * (1024 + 32 * 2 * 64 * 4)
     assert ws(1 << 20, env={"max_steps": 128}) == big and ws(1 << 20, env={"max_steps": 129}) > big
-    assert ws(1 << 20, q=1) == 16384                       # generic kernel: nothing kept in the workspace
+    # float64 tables are twice the LDS per game: 11 resident waves per CU
+    assert ws(1 << 20, q=1) == 16384 + 11 * 256 * (1024 + 32 * 2 * 64 * 4)
+    c3 = json.loads(json.dumps(CFG)); c3["agents"].append(dict(CFG_AGENT)); c3["environment"]["nplayers"] = 3
+    cfg3, _ = _lib.cfg_from_config(c3, 1 << 20, 0)
+    assert lib.thrl_workspace_bytes(ctypes.byref(cfg3)) == 16384          # generic kernel: nothing kept in the workspace
     bad, _ = _lib.cfg_from_config(CFG, 4, 0)
     bad.n_agents = 0
     assert lib.thrl_workspace_bytes(ctypes.byref(bad)) == 0
@@ -133,7 +139,7 @@ def test_error_codes_never_throw(lib):
     assert lib.thrl_replay_mem_bytes(ctypes.byref(cfg)) == 0
     cfg, _ = _lib.cfg_from_config(CFG, 4, 0)
     # NULL buffers are rejected before anything touches the device
-    assert lib.thrl_qtable_init(ctypes.byref(cfg), None, None, None, 0, 0, None) == -2
+    assert lib.thrl_qtable_init(ctypes.byref(cfg), None, None, None, 0, 0, None, None) == -2
     run = _lib.Run(); bufs = _lib.Buffers()
     assert lib.thrl_qtable_episodes(ctypes.byref(cfg), ctypes.byref(bufs), ctypes.byref(run), None) == -2
     assert lib.thrl_play_greedy(ctypes.byref(cfg), None, None, 1, 0, 0, None, None, None) == -2

@@ -67,6 +67,9 @@ class Mixed(ctypes.Structure):
         ("buf_reward", ctypes.c_void_p * MAXA), ("buf_nprice", ctypes.c_void_p * MAXA),
         ("buf_scratch", ctypes.c_void_p * MAXA), ("buf_len", ctypes.c_int32 * MAXA),
         ("min_memory", ctypes.c_int32 * MAXA), ("count", ctypes.c_int32 * MAXA),
+        ("sweep_gamma", ctypes.c_void_p), ("sweep_alpha", ctypes.c_void_p),
+        ("sweep_eps_end", ctypes.c_void_p), ("sweep_eps_step", ctypes.c_void_p),
+        ("sweep_eps", ctypes.c_void_p), ("sweep_noise_prob", ctypes.c_void_p),
     ]
 
 
@@ -125,7 +128,7 @@ def load():
     L.thrl_select_kernel.restype = ctypes.c_int
     L.thrl_select_kernel.argtypes = [cfgp, ctypes.c_int]
     L.thrl_qtable_init.restype = ctypes.c_int
-    L.thrl_qtable_init.argtypes = [cfgp, vp, vp, vp, u64, u64, vp]
+    L.thrl_qtable_init.argtypes = [cfgp, vp, vp, vp, u64, u64, vp, vp]
     L.thrl_qtable_episodes.restype = ctypes.c_int
     L.thrl_qtable_episodes.argtypes = [cfgp, ctypes.POINTER(Buffers), ctypes.POINTER(Run), vp]
     L.thrl_play_greedy.restype = ctypes.c_int
@@ -148,7 +151,7 @@ def load():
     L.thrl_nn_act.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     L.thrl_nn_reinforce_train.restype = ctypes.c_int
     L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp,
-                                          dbl, dbl, dbl, vp, vp]
+                                          dbl, dbl, dbl, vp, vp, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
     L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]
     L.thrl_cac_init.restype = ctypes.c_int
@@ -157,7 +160,7 @@ def load():
     L.thrl_cac_act.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.thrl_cac_train.restype = ctypes.c_int
     L.thrl_cac_train.argtypes = [ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
-                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
+                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
     L.thrl_ac_param_count.restype = ctypes.c_size_t
     L.thrl_ac_param_count.argtypes = [ctypes.c_int]
     L.thrl_ac_init.restype = ctypes.c_int
@@ -166,10 +169,10 @@ def load():
     L.thrl_ac_act.argtypes = L.thrl_nn_act.argtypes
     L.thrl_ac_train.restype = ctypes.c_int
     L.thrl_ac_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
-                                ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
+                                ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
     L.thrl_mixed_episodes.restype = ctypes.c_int
     L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
-    if L.thrl_version() != 1:
+    if L.thrl_version() != 2:
         raise ThrlError("th_rl_amd: ABI version mismatch (%d)" % L.thrl_version())
     _lib = L
     return L

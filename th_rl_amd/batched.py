@@ -74,7 +74,8 @@ class GameBatch:
     def set_sweep(self, sweep):
         """Per-game hyper-parameters: dict of arrays [N, G] (or [G]: same for every agent) for
         gamma / alpha / eps_end / eps_step / eps (starting epsilon), and [G] for noise_prob.
-        Keys that are absent keep the config's scalar for every game."""
+        Keys that are absent keep the config's scalar for every game.  Call before init_tables()
+        when gamma is swept (the initial table offset depends on it)."""
         torch = _torch()
         for k, v in sweep.items():
             if k not in self.SWEEP_KEYS:
@@ -114,11 +115,14 @@ class GameBatch:
 
     # ------------------------------------------------------------------ init / upload
     def init_tables(self):
-        """QTable.__init__ + env.reset() for all games from Philox (thrl_qtable_init)."""
+        """QTable.__init__ + env.reset() for all games from Philox (thrl_qtable_init).  With a gamma
+        sweep every game's table starts at ITS 12.5/(1-gamma) (agents.py:29), so game g of the sweep is
+        the game a plain run of that config would initialise."""
         torch = _torch()
         with torch.cuda.device(self.device):
             rc = self.L.thrl_qtable_init(ctypes.byref(self.cfg), self._ptr(self.q), self._ptr(self.counter),
-                                         self._ptr(self.state), self.seed, self.game_offset, self._stream())
+                                         self._ptr(self.state), self.seed, self.game_offset,
+                                         self._ptr(self.sweep.get("gamma")), self._stream())
         _lib.check(rc, "thrl_qtable_init")
         self.initialized = True
         return self

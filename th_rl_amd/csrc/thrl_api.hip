@@ -164,7 +164,6 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     memset(&p, 0, sizeof(p));
 #define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
     if (c->n_agents != 2) NO("needs exactly 2 agents");
-    if (c->q_dtype != 0) NO("float32 tables only");
     if (c->n_states[0] != c->n_states[1] || c->n_actions[0] != c->n_actions[1] ||
         c->max_state[0] != c->max_state[1]) NO("agents must share the state/action grid sizes");
     const int A = c->n_actions[0], T = c->max_steps;
@@ -202,8 +201,8 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     if (p.win_rows + 2 > 128) NO("reachable row window > 126 rows");
     const WaveLut L = wave_lut_layout(A);
     p.lut_bytes = L.lds_bytes;          // LDS-staged part of the LUT image
-    p.game_lds_bytes = 2 * (p.win_rows + 2) * A * 4;
-    // choose waves/block to maximise resident waves per CU (LDS-bound), block LDS <= 64 KiB
+    p.game_lds_bytes = 2 * (p.win_rows + 2) * A * (c->q_dtype == 1 ? 8 : 4);
+    // choose waves/block to maximise resident waves per CU (LDS-bound); a block may take the whole CU's LDS
     int best_w = 0, best_total = 0, best_b = 0;
     const DevInfo dv = dev_info();
     int cap_waves = dv.waves_per_cu;
@@ -212,12 +211,13 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     // are dealt to the CU's 4 SIMDs in turn, so among equal totals blocks of 4k waves are preferred
     // (they load the SIMDs evenly); with games handed out dynamically an uneven split only costs the
     // crowded SIMD's waves some speed (noise window: 3 x 5 waves measured 12 % faster than 3 x 4).
-    // register limit: the kernel variants are compiled for 5 waves/SIMD (4 with noise or T > 128)
-    const int reg_waves = 4 * ((c->noise_prob > 0.0 || c->max_steps > 128) ? 4 : 5);
+    // register limit: the float32 variants are compiled for 5 waves/SIMD (4 with noise or T > 128),
+    // the float64 ones (twice the LDS per game) for 3
+    const int reg_waves = 4 * (c->q_dtype == 1 ? 3 : ((c->noise_prob > 0.0 || c->max_steps > 128) ? 4 : 5));
     if (cap_waves > reg_waves) cap_waves = reg_waves;
     for (int w = 1; w <= 16; w++) {
         const int lds = p.lut_bytes + w * p.game_lds_bytes;
-        if (lds > 65536) break;
+        if (lds > dv.lds_per_cu) break;
         int b = dv.lds_per_cu / (((lds + 511) / 512) * 512);
         if (b * w > cap_waves) b = cap_waves / w;
         if (b < 1) continue;
@@ -296,7 +296,7 @@ int thrl_select_kernel(const thrl_cfg* c, int injected) {
 }
 
 int thrl_qtable_init(const thrl_cfg* c, void* q, int32_t* counter, double* state, uint64_t seed,
-                     uint64_t game_offset, void* stream) {
+                     uint64_t game_offset, const double* sweep_gamma, void* stream) {
     int rc = validate(c);
     if (rc) return rc;
     if (!q || !state) return fail(THRL_ERR_NULL, "q/state is NULL");
@@ -305,13 +305,16 @@ int thrl_qtable_init(const thrl_cfg* c, void* q, int32_t* counter, double* state
     a.G = c->n_games; a.N = c->n_agents; a.stride = (int64_t)thrl_table_stride(c); a.env_a = c->env_a;
     fill_agents(c, a.ag, nullptr);
     a.q = q; a.counter = counter; a.state = state; a.seed = seed; a.game_offset = game_offset;
+    a.sw_gamma = sweep_gamma;
     const int e = launch_init(a, c->q_dtype, (hipStream_t)stream);
     return e ? hip_fail(e, "k_init launch") : THRL_OK;
 }
 
 static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, hipStream_t s) {
-    if (b->sweep_gamma || b->sweep_alpha || b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob)
-        return fail(THRL_ERR_UNSUPPORTED, "per-game sweeps run on the fused wave kernel only (this config/request needs the generic kernel)");
+    if ((b->sweep_eps_end || b->sweep_eps_step) && !b->sweep_eps)
+        return fail(THRL_ERR_NULL, "sweep_eps_end / sweep_eps_step need the per-game epsilon state sweep_eps");
+    if (b->sweep_noise_prob && !(c->noise_prob > 0.0))
+        return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it switches the noise draws on)");
     const int capmax = capmax_of(c);
     const size_t need = thrl_replay_mem_bytes(c);
     if (!b->replay_mem || b->replay_mem_bytes < need)
@@ -341,6 +344,8 @@ static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, 
     a.seed = run->seed; a.game_offset = run->game_offset; a.first_episode = run->first_episode;
     a.n_episodes = run->n_episodes;
     for (int i = 0; i < THRL_MAXA; i++) { a.eps0[i] = run->eps[i]; a.cnt0[i] = run->mem_count[i]; }
+    a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
+    a.sw_eps_step = b->sweep_eps_step; a.sw_eps = b->sweep_eps; a.sw_noise_prob = b->sweep_noise_prob;
     const int nlog = run->n_episodes * c->n_agents;
     if (a.sum_reward) {
         hipError_t e1 = hipMemsetAsync(a.sum_reward, 0, sizeof(double) * nlog, s);
@@ -388,7 +393,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     AgentParams ag[THRL_MAXA];
     fill_agents(c, ag, &a.env);
     a.ag[0] = ag[0]; a.ag[1] = ag[1];
-    a.q = (float*)b->q; a.counter = b->counter; a.state = b->state;
+    a.q = b->q; a.counter = b->counter; a.state = b->state;
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut_ns = lut;
     const WaveWs ws = wave_workspace(c, p);
@@ -442,7 +447,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
                 run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];
             }
         if (hipMemsetAsync(a.next_game, 0, sizeof(int32_t), s) != hipSuccess) return hip_fail((int)hipGetLastError(), "hipMemsetAsync");
-        e = launch_wave(a, grid, block, lds, s);
+        e = launch_wave(a, c->q_dtype, grid, block, lds, s);
         if (e) return hip_fail(e, "k_wave_episodes launch");
         if (b->reward_log || b->action_log) {
             e = launch_wave_reduce(a.partial, a.log_scale, a.total_waves, n, c->n_games,
@@ -619,7 +624,8 @@ int thrl_ac_act(int n_games, int n_actions, const float* params, const double* p
 
 int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
                   const double* price, const int32_t* action, const double* reward, const double* next_price,
-                  double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+                  double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
+                  float* grad_out, void* stream) {
     int rc = nn_check(n_games, n_actions);
     if (rc) return rc;
     if (!params || !adam_m || !adam_v || !price || !action || !reward || !next_price)
@@ -629,7 +635,8 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
     if (nn_train_lds_bytes(n_actions, n, 1) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
     const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, next_price,
-                                  (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
+                                  (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train<AC> launch") : THRL_OK;
 }
 
@@ -645,7 +652,8 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
 
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step,
                             int32_t n, const double* price, const int32_t* action, const double* reward,
-                            double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+                            double gamma, double entropy_coef, double lr, const double* sweep_gamma,
+                            const double* sweep_entropy, float* grad_out, void* stream) {
     int rc = nn_check(n_games, n_actions);
     if (rc) return rc;
     if (!params || !adam_m || !adam_v || !price || !action || !reward) return fail(THRL_ERR_NULL, "a required pointer is NULL");
@@ -654,7 +662,8 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
     if (nn_train_lds_bytes(n_actions, n, 0) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
     const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, nullptr,
-                                  (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
+                                  (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
 }
 
@@ -690,6 +699,12 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
         a.buf_len[i] = mx->buf_len[i]; a.min_memory[i] = mx->min_memory[i]; a.count0[i] = mx->count[i];
         a.eps0[i] = run->eps[i];
     }
+    if ((mx->sweep_eps_end || mx->sweep_eps_step) && !mx->sweep_eps)
+        return fail(THRL_ERR_NULL, "sweep_eps_end / sweep_eps_step need the per-game epsilon state sweep_eps");
+    if (mx->sweep_noise_prob && !(c->noise_prob > 0.0))
+        return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it switches the noise draws on)");
+    a.sw_gamma = mx->sweep_gamma; a.sw_alpha = mx->sweep_alpha; a.sw_eps_end = mx->sweep_eps_end;
+    a.sw_eps_step = mx->sweep_eps_step; a.sw_eps = mx->sweep_eps; a.sw_noise_prob = mx->sweep_noise_prob;
     const char* why = "";
     if (plan_mixed(a, c->q_dtype, &why)) return fail(THRL_ERR_UNSUPPORTED, "thrl_mixed_episodes: %s", why);
     const int e = launch_mixed(a, c->q_dtype, (hipStream_t)stream);
@@ -730,7 +745,8 @@ int thrl_cac_act(int n_games, const float* params, const double* price, const do
 
 int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
                    const double* price, const float* action, const double* reward, const double* next_price,
-                   double gamma, double entropy_coef, double lr, float* grad_out, void* stream) {
+                   double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
+                   float* grad_out, void* stream) {
     if (n_games < 1) return fail(THRL_ERR_BAD_CONFIG, "n_games=%d must be >= 1", n_games);
     if (!params || !adam_m || !adam_v || !price || !action || !reward || !next_price)
         return fail(THRL_ERR_NULL, "a required pointer is NULL");
@@ -738,7 +754,8 @@ int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int
         return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions: need 2 <= n and the batch in LDS (n <= ~5600)", n);
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
     const int e = launch_cac_train(n_games, params, adam_m, adam_v, step, n, price, action, reward, next_price,
-                                   (float)gamma, (float)entropy_coef, (float)lr, grad_out, (hipStream_t)stream);
+                                   (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
+                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_cac_train launch") : THRL_OK;
 }
 

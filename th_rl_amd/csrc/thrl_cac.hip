@@ -87,8 +87,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 __global__ void __launch_bounds__(256) k_cac_train(int G, float* __restrict__ params, float* __restrict__ adam_m,
         float* __restrict__ adam_v, int step, int N, const double* __restrict__ price, const float* __restrict__ action,
         const double* __restrict__ reward, const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
-        float* __restrict__ grad_out) {
+        const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cac[];
+    if (gamma_g) gamma = (float)gamma_g[blockIdx.x];        // per-game sweeps
+    if (ent_g) ent_coef = (float)ent_g[blockIdx.x];
     double* redd = reinterpret_cast<double*>(smem_cac);     // [4]
     float* red = reinterpret_cast<float*>(redd + 4);        // [8]
     float* ws = red + 8;                                    // [5][kH]: w1 b1 wmu wstd wv
@@ -192,14 +194,14 @@ int launch_cac_act(int G, const float* params, const double* price, const double
 }
 size_t cac_train_lds_bytes(int N) { return 4 * sizeof(double) + sizeof(float) * (8 + 5 * (size_t)kH + 7 * (size_t)N); }
 int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, const double* price, const float* action,
-                     const double* reward, const double* nprice, float gamma, float ent, float lr, float* grad,
-                     hipStream_t s) {
+                     const double* reward, const double* nprice, float gamma, float ent, float lr,
+                     const double* gamma_g, const double* ent_g, float* grad, hipStream_t s) {
     const size_t lds = cac_train_lds_bytes(N);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cac_train), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_cac_train, dim3(G), dim3(256), lds, s, G, params, m, v, step, N, price, action, reward, nprice,
-                       gamma, ent, lr, grad);
+                       gamma, ent, lr, gamma_g, ent_g, grad);
     return (int)hipGetLastError();
 }
 

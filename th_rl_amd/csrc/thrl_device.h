@@ -121,6 +121,30 @@ __device__ __forceinline__ float td_value(float ov, double re, float nm, const A
     return __fmaf_rn(p.alpha_gamma_f, nm, b);
 }
 
+// the same with explicit coefficients (per-game sweeps: alpha / gamma come from arrays)
+struct TdCoef {
+    double alpha, gamma, one_minus_alpha;
+    float alpha_f, one_minus_alpha_f, alpha_gamma_f;
+};
+__device__ __forceinline__ TdCoef td_coef(const AgentParams& p) {
+    return TdCoef{p.alpha, p.gamma, p.one_minus_alpha, p.alpha_f, p.one_minus_alpha_f, p.alpha_gamma_f};
+}
+__device__ __forceinline__ TdCoef td_coef(double alpha, double gamma) {      // as fill_agents() derives them on the host
+    const double oma = __dsub_rn(1.0, alpha);
+    const float af = (float)alpha, gf = (float)gamma;
+    return TdCoef{alpha, gamma, oma, af, (float)oma, __fmul_rn(af, gf)};
+}
+__device__ __forceinline__ double td_value(double ov, double re, double nm, const TdCoef& c) {
+    const double t4 = __dmul_rn(c.one_minus_alpha, ov);
+    const double t2 = __dadd_rn(re, __dmul_rn(c.gamma, nm));
+    return __dadd_rn(t4, __dmul_rn(c.alpha, t2));
+}
+__device__ __forceinline__ float td_value(float ov, double re, float nm, const TdCoef& c) {
+    const float t4 = __fmul_rn(c.one_minus_alpha_f, ov);
+    const float b = __fmaf_rn(c.alpha_f, (float)re, t4);
+    return __fmaf_rn(c.alpha_gamma_f, nm, b);
+}
+
 template <typename T>
 __device__ __forceinline__ int argmax_row(const T* __restrict__ row, int n) {
     int b = 0;

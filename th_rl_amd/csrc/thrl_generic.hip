@@ -33,7 +33,11 @@ __global__ void __launch_bounds__(256) k_generic_episodes(const GenericArgs a) {
     double eps[THRL_MAXA];
     int cnt[THRL_MAXA];
 #pragma unroll
-    for (int i = 0; i < THRL_MAXA; i++) { eps[i] = a.eps0[i]; cnt[i] = a.cnt0[i]; }
+    for (int i = 0; i < THRL_MAXA; i++) {
+        eps[i] = (a.sw_eps && i < N) ? a.sw_eps[(size_t)i * G + gc] : a.eps0[i];      // per-game sweeps (thrl_buffers.sweep_*)
+        cnt[i] = a.cnt0[i];
+    }
+    const double noise_prob_g = a.sw_noise_prob ? a.sw_noise_prob[gc] : a.env.noise_prob;
     double price = a.state[gc];
 
     for (int e = 0; e < a.n_episodes; e++) {
@@ -81,7 +85,7 @@ __global__ void __launch_bounds__(256) k_generic_episodes(const GenericArgs a) {
                     nu = u01_32(xn.x);
                     na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
                 }
-                if (nu < a.env.noise_prob) a_eff = na;
+                if (nu < noise_prob_g) a_eff = na;
             }
             const double next_price = env_step<THRL_MAXA>(a.env, N, scaled, a_eff, rew);
 #pragma unroll
@@ -116,6 +120,9 @@ __global__ void __launch_bounds__(256) k_generic_episodes(const GenericArgs a) {
                 if (active) {
                     const int start = cnt[i] <= p.capacity ? 0 : cnt[i] % p.capacity;
                     T* __restrict__ tab = qg + p.table_off;
+                    const TdCoef tc = (a.sw_alpha || a.sw_gamma)
+                        ? td_coef(a.sw_alpha ? a.sw_alpha[(size_t)i * G + gc] : p.alpha, a.sw_gamma ? a.sw_gamma[(size_t)i * G + gc] : p.gamma)
+                        : td_coef(p);
                     int pos = start;
                     for (int k = 0; k < len; k++) {            // old_value snapshot (:67)
                         const size_t m = ((size_t)pos * N + i) * G + g;
@@ -127,14 +134,16 @@ __global__ void __launch_bounds__(256) k_generic_episodes(const GenericArgs a) {
                         const size_t m = ((size_t)pos * N + i) * G + g;
                         const int st = a.mem.s[m], ac = a.mem.a[m], ns = a.mem.ns[m];
                         const T nm = max_row(tab + ns * p.n_actions, p.n_actions);
-                        tab[st * p.n_actions + ac] = td_value((T)a.mem.ov[m], a.mem.r[m], nm, p);
+                        tab[st * p.n_actions + ac] = td_value((T)a.mem.ov[m], a.mem.r[m], nm, tc);
                         if (cg) cg[p.table_off + st * p.n_actions + ac] += 1;
                         pos = pos + 1 == p.capacity ? 0 : pos + 1;
                     }
                 }
                 cnt[i] = 0;                                     // memory.empty() (:77)
             }
-            eps[i] = __dadd_rn(p.eps_end, __dmul_rn(__dsub_rn(eps[i], p.eps_end), p.eps_step));   // (:78)
+            const double eend = a.sw_eps_end ? a.sw_eps_end[(size_t)i * G + gc] : p.eps_end;
+            const double estep = a.sw_eps_step ? a.sw_eps_step[(size_t)i * G + gc] : p.eps_step;
+            eps[i] = __dadd_rn(eend, __dmul_rn(__dsub_rn(eps[i], eend), estep));   // (:78)
         }
 
         // ---- logs (trainer.py:65-66 rows; mean over games is an API extension)
@@ -156,7 +165,11 @@ __global__ void __launch_bounds__(256) k_generic_episodes(const GenericArgs a) {
             }
         }
     }
-    if (active) a.state[g] = price;
+    if (active) {
+        a.state[g] = price;
+        if (a.sw_eps)
+            for (int i = 0; i < N; i++) a.sw_eps[(size_t)i * G + g] = eps[i];
+    }
 }
 
 __global__ void k_finalize_logs(double* sr, double* sa, int n, double G) {

@@ -35,6 +35,9 @@ struct GenericArgs {
     int32_t n_episodes;
     double eps0[THRL_MAXA];
     int32_t cnt0[THRL_MAXA];
+    // per-game sweeps (null = the scalar parameters above), [N][G] except noise_prob [G]
+    const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
+    double* sw_eps; const double* sw_noise_prob;
 };
 
 // ---- fused wave-per-game kernel (thrl_wave.hip) -----------------------------
@@ -51,7 +54,7 @@ struct WaveArgs {
     int64_t stride;
     EnvParams env;
     AgentParams ag[2];
-    float* q;
+    void* q;                        // float or double tables (the kernel variant's QT)
     int32_t* counter;
     double* state;
     const unsigned char* lut_ns;    // device: payoff LUT image (thrl_wave_lut.h), lut_bytes long
@@ -74,7 +77,14 @@ struct WaveArgs {
 int launch_generic(const GenericArgs& a, int q_dtype, hipStream_t s);
 int launch_finalize_logs(double* sum_reward, double* sum_action, int n, int G, hipStream_t s);
 int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s);
-int launch_wave(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave(const WaveArgs& a, int q_dtype, int grid, int block, size_t lds_bytes, hipStream_t s);
+// one translation unit per (table type, NOISE, SWEEP) family of k_wave_episodes instantiations
+int launch_wave_f32_plain(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f32_noise(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f32_sweep(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_plain(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_noise(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_sweep(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_reduce(const long long* partial, const double* log_scale, int total_waves, int n_episodes, int G,
                        double* reward_log, double* action_log, hipStream_t s);
 
@@ -85,6 +95,7 @@ struct InitArgs {
     AgentParams ag[THRL_MAXA];
     void* q; int32_t* counter; double* state;
     uint64_t seed, game_offset;
+    const double* sw_gamma;         // per-game gamma [N][G] (the table offset 12.5/(1-gamma), agents.py:29) or null
 };
 int launch_init(const InitArgs& a, int q_dtype, hipStream_t s);
 
@@ -139,6 +150,9 @@ struct MixedArgs {
     int32_t lds_bytes;
     int32_t memo_lds_byte0, memo_on, memo_k;                                   // memoised policy CDFs [n_r][64][APAD] floats
     int32_t n_cac, cac_lds_byte0;                                      // CAC networks (kind 3) live in LDS after the tables
+    // per-game sweeps of the QTable agents / the env (null = the scalars above), [N][G] except noise_prob [G]
+    const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
+    double* sw_eps; const double* sw_noise_prob;
 };
 // fills n_r / ragent / lds_off / lds_bytes; returns 0 or -1 with a reason when the config does not fit
 int plan_mixed(MixedArgs& a, int q_dtype, const char** why);
@@ -150,6 +164,7 @@ size_t nn_train_lds_bytes(int A, int N, int value_head);
 // nprice != NULL: ActorCritic update (value head, params stride P + 257); NULL: Reinforce
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
+                    const double* gamma_g, const double* ent_g,      // per-game gamma / entropy coefficient [G] or null
                     float* grad,
                     hipStream_t s);
 // ---- continuous actor-critic agent CAC (thrl_cac.hip)
@@ -158,8 +173,8 @@ int launch_cac_act(int G, const float* params, const double* price, const double
                    float* mu, float* sd, float* v, hipStream_t s);
 size_t cac_train_lds_bytes(int N);
 int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, const double* price, const float* action,
-                     const double* reward, const double* nprice, float gamma, float ent, float lr, float* grad,
-                     hipStream_t s);
+                     const double* reward, const double* nprice, float gamma, float ent, float lr,
+                     const double* gamma_g, const double* ent_g, float* grad, hipStream_t s);
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,
                     double noise_lo, const int32_t* nA, double* u, int8_t* ch, double* u2, double* nu, double* na,
                     hipStream_t s);

@@ -71,8 +71,15 @@ k_mixed_wave(const MixedArgs a) {
             // Reinforce.scale (agents.py:153-157): action / actions * (hi - lo) + lo
             sc_tab[i * 64 + lane] = __dadd_rn(__dmul_rn(__ddiv_rn((double)lane, (double)p.n_actions), p.act_span), p.act_lo);
         }
-        if (lane == i) { eps_l = a.eps0[i]; cnt_l = a.count0[i]; cap_l = a.buf_len[i]; }
+        if (lane == i) { eps_l = a.sw_eps ? a.sw_eps[(size_t)i * a.G + g] : a.eps0[i]; cnt_l = a.count0[i]; cap_l = a.buf_len[i]; }
     }
+    // per-game sweeps of the QTable agents' schedule (lane i = agent i) and of the env noise
+    double eend_l = 0.0, estep_l = 0.0;
+    if (lane < a.N) {
+        eend_l = a.sw_eps_end ? a.sw_eps_end[(size_t)lane * a.G + g] : a.ag[lane].eps_end;
+        estep_l = a.sw_eps_step ? a.sw_eps_step[(size_t)lane * a.G + g] : a.ag[lane].eps_step;
+    }
+    const double noise_prob_g = a.sw_noise_prob ? a.sw_noise_prob[g] : a.env.noise_prob;
     if (NR >= 1) {
         const int A = a.ag[a.ragent[0]].n_actions;
         policy_load(net0, a.nn_params[a.ragent[0]] + (int64_t)g * a.nn_stride[a.ragent[0]], A, lane);
@@ -174,7 +181,7 @@ k_mixed_wave(const MixedArgs a) {
             double a_eff = a.env.a;
             if (noisy) {
                 const uint32_t nx = lane_u32(xn.x, tl), ny = lane_u32(xn.y, tl);
-                if (u01_32(nx) < a.env.noise_prob)
+                if (u01_32(nx) < noise_prob_g)
                     a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(ny)));
             }
             const double A_l = __dmul_rn(a.env.ratio, scaled_l);
@@ -212,6 +219,9 @@ k_mixed_wave(const MixedArgs a) {
             const int len = cnt < cap ? cnt : cap;
             if (cap > 0 && len >= a.min_memory[i]) {
                 T* const tab = lds + a.lds_off[i];
+                const TdCoef tc = (a.sw_alpha || a.sw_gamma)
+                    ? td_coef(a.sw_alpha ? a.sw_alpha[(size_t)i * G + g] : p.alpha, a.sw_gamma ? a.sw_gamma[(size_t)i * G + g] : p.gamma)
+                    : td_coef(p);
                 const int start = cnt <= cap ? 0 : cnt % cap;
                 const int A = p.n_actions;
                 const double* __restrict__ bp = a.buf_price[i]; const double* __restrict__ bn = a.buf_nprice[i];
@@ -240,7 +250,7 @@ k_mixed_wave(const MixedArgs a) {
                         const double re_k = lane_f64(re, k);
                         const T ov_k = lane_val(ov, k);
                         const T nm = wave_allmax(lane < A ? tab[ns_k * A + lane] : neg_inf<T>());
-                        const T nv = td_value(ov_k, re_k, nm, p);
+                        const T nv = td_value(ov_k, re_k, nm, tc);
                         if (lane == 0) {
                             tab[st_k * A + ac_k] = nv;
                             if (cg) atomicAdd(&cg[p.table_off + st_k * A + ac_k], 1);
@@ -250,7 +260,7 @@ k_mixed_wave(const MixedArgs a) {
                 }
                 if (lane == i) cnt_l = 0;
             }
-            if (lane == i) eps_l = __dadd_rn(p.eps_end, __dmul_rn(__dsub_rn(eps_l, p.eps_end), p.eps_step));
+            if (lane == i) eps_l = __dadd_rn(eend_l, __dmul_rn(__dsub_rn(eps_l, eend_l), estep_l));
         }
         if (lane < N) a.game_reward_log[((size_t)e * N + lane) * G + g] = acc;
         if (lane >= 32 && lane < 32 + N) a.game_action_log[((size_t)e * N + (lane - 32)) * G + g] = acc;
@@ -264,6 +274,7 @@ k_mixed_wave(const MixedArgs a) {
         for (int e = lane; e < n; e += 64) qg[p.table_off + e] = lds[a.lds_off[i] + e];
     }
     if (lane == 0) a.state[g] = price;
+    if (a.sw_eps && lane < N && a.kind[lane] == 0) a.sw_eps[(size_t)lane * G + g] = eps_l;
 }
 
 template <typename T, int NR, int APAD, int NA, bool CAC, bool MEMO>

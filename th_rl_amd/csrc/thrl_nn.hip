@@ -81,8 +81,11 @@ template <int kPad, bool AC>
 __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
-        const double* __restrict__ nprice, float gamma, float ent_coef, float lr, float* __restrict__ grad_out) {
+        const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
+        const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
+    if (gamma_g) gamma = (float)gamma_g[blockIdx.x];        // per-game sweeps (main.py:13-21 as one batch)
+    if (ent_g) ent_coef = (float)ent_g[blockIdx.x];
     const int NX = train_xs_len(N);
     float* W2t = reinterpret_cast<float*>(smem_nn);         // [kH][kPad]  fc_pi.weight transposed
     float* dz = W2t + kH * kPad;                            // [kChunk][kPad]
@@ -524,14 +527,14 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
-                    float* grad, hipStream_t s) {
+                    const double* gamma_g, const double* ent_g, float* grad, hipStream_t s) {
     const size_t lds = nn_train_lds_bytes(A, N, nprice != nullptr);
     auto kern = nprice ? (A <= 24 ? k_nn_reinforce_train<24, true> : k_nn_reinforce_train<32, true>)
                        : (A <= 24 ? k_nn_reinforce_train<24, false> : k_nn_reinforce_train<32, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price, action, reward, nprice,
-                       gamma, ent, lr, grad);
+                       gamma, ent, lr, gamma_g, ent_g, grad);
     return (int)hipGetLastError();
 }
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,

@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(256) k_init(const InitArgs a) {
 #pragma unroll
         for (int k = 1; k < THRL_MAXA; k++)
             if (k < a.N && jj >= a.ag[k].table_off) i = k;
-        const double base = __ddiv_rn(12.5, __dsub_rn(1.0, a.ag[i].gamma));
+        const double gamma = a.sw_gamma ? a.sw_gamma[(size_t)i * a.G + g] : a.ag[i].gamma;
+        const double base = __ddiv_rn(12.5, __dsub_rn(1.0, gamma));
         const u32x4 x = draw(a.seed, gid, 0xFFFFFFFFu, (uint32_t)(jj >> 2), kStreamInitTable);
         const uint32_t xa = (jj & 2) ? x.z : x.x, xb = (jj & 2) ? x.w : x.y;
         const double u1 = ((double)xa + 0.5) * 0x1p-32;

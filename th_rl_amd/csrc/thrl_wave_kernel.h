@@ -1,0 +1,780 @@
+// thrl_wave_kernel.h -- fused episode kernel for gfx950: ONE WAVEFRONT PER GAME (template body).
+//
+// The performance path for the reference's headline shape: 2 QTable agents with the same grid
+// sizes on one NoisyPriceState.  Table type QT = float (the metric's dtype) or double (the
+// reference's own numerics, agents.py:29).  Same semantics as thrl_generic.hip and bit-identical
+// results to it and to the oracle in the same dtype: trainer.train_one's loop (th_rl/trainer.py:46-70)
+// with QTable.sample_action (agents.py:80-89), scale (:51-57), NoisyPriceState.step
+// (environments.py:25-39), ReplayBuffer append/replay/empty (buffers.py) and QTable.train_net
+// (agents.py:59-78) fused, for `n_episodes` episodes per launch.
+//
+// MI355X mapping:
+//   * a wave owns one game for the whole launch; its two agents' Q-table WINDOWS (only the rows the
+//     payoff grid can reach, + 2 spill rows for an arbitrary initial state) are streamed coalesced
+//     HBM -> LDS once, stay resident for all episodes of the launch, and are streamed back once;
+//   * lanes 0-31 serve agent 0, lanes 32-63 agent 1;
+//   * the discretised action grid (next-state row + price per action pair) is a LUT staged in LDS
+//     once per block ("payoff LUT");
+//   * everything that is not on a serial chain is done lane-parallel over the T steps of an episode
+//     (lane = step) or over the table rows (lane = row): Philox draws, per-row greedy actions, reward /
+//     old-value gathers, log sums, the replay schedule;
+//   * play chain: s <- next_row_t[s], one v_readlane per step;
+//   * replay (train_net's serial loop, agents.py:68-76) runs FOUR transitions per pass: each 32-lane
+//     half is split into four 8-lane groups, group k reads the whole next-state row of transition
+//     4g+k (3 columns per lane), one v_max3 + three DPP steps give every lane of the group that row's
+//     max, and the lane holding transition 4g+k's operands computes the TD value and stores it.
+//     A pass is legal when no transition in it reads a row, or rewrites a cell, that an earlier
+//     transition of the same pass writes; the schedule (where a group of four must be cut into
+//     several passes) is computed lane-parallel before the loop, so results are exactly those of the
+//     serial loop.
+#pragma once
+#include "thrl_kernels.h"
+#include "thrl_wave_lut.h"
+
+namespace thrl {
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+// lanes<32 of the result: lanes 0-31 of a ; lanes>=32: lanes 0-31 of b   (.x)
+// and the same for the upper halves (.y): one v_permlane32_swap.
+__device__ __forceinline__ v2u pack_halves(unsigned a, unsigned b) {
+    return __builtin_amdgcn_permlane32_swap(a, b, false, false);
+}
+
+// LDS access by 32-bit LDS address (address space 3): no generic-pointer arithmetic
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <typename QT>
+__device__ __forceinline__ QT lds_load(unsigned addr) {
+    typedef __attribute__((address_space(3))) QT lds_t;
+    return *(const lds_t*)(uintptr_t)addr;
+}
+template <typename QT>
+__device__ __forceinline__ void lds_store(unsigned addr, QT v) {
+    typedef __attribute__((address_space(3))) QT lds_t;
+    *(lds_t*)(uintptr_t)addr = v;
+}
+
+__device__ __forceinline__ unsigned bperm(unsigned byte_sel, unsigned v) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_sel, (int)v);
+}
+
+// DPP move of a double (two dword moves)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov64(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// max over each aligned group of 8 lanes, result in every lane of the group.
+// float: three single-instruction DPP max steps (xor 1, xor 2 inside the quad, then the mirror of
+// the 8-lane half row).  The s_nop 1 before each are the 2 wait states a DPP read of a just-written
+// VGPR needs (hipcc does not look inside asm statements).
+__device__ __forceinline__ float group8_allmax(float v) {
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ double group8_allmax(double v) {
+    v = fmax(v, dpp_mov64<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_mov64<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_mov64<0x141>(v));      // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float max_of(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_of(double a, double b) { return fmax(a, b); }
+
+// Sum FOUR per-lane doubles over the 64 lanes in one pass ("transpose" reduction):
+// returns, in every lane L, the wave total of quantity (L & 3) where the quantities are
+// ordered (q0, q1, q2, q3).  7 double adds instead of 24, no LDS traffic.
+__device__ __forceinline__ double wave_sum4(double q0, double q1, double q2, double q3, int lane) {
+    // step 1 (partner lane^1): even lanes keep (q0,q2), odd lanes keep (q1,q3)
+    const bool odd = lane & 1;
+    const double k0 = odd ? q1 : q0, k1 = odd ? q3 : q2;      // kept
+    const double s0 = odd ? q0 : q1, s1 = odd ? q2 : q3;      // what the partner keeps
+    const double a0 = k0 + dpp_mov64<0xB1>(s0);               // quad_perm [1,0,3,2]
+    const double a1 = k1 + dpp_mov64<0xB1>(s1);
+    // step 2 (partner lane^2): bit1 == 0 keeps the first, bit1 == 1 keeps the second
+    const bool b1 = lane & 2;
+    const double kk = b1 ? a1 : a0, ss = b1 ? a0 : a1;
+    double v = kk + dpp_mov64<0x4E>(ss);                      // quad_perm [2,3,0,1]
+    // now lane L holds quantity (L&3) summed over its quad; rotate-add within the 16-lane row
+    v = v + dpp_mov64<0x124>(v);                              // row_ror:4
+    v = v + dpp_mov64<0x128>(v);                              // row_ror:8
+    // across the four rows: swap-add with v_permlane16_swap / v_permlane32_swap
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane16_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane16_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane32_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane32_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// v = lane `lane` of `old` replaced by the (uniform) value `val`: one v_writelane_b32 with the
+// lane select in M0 (two different SGPR operands would break the gfx9 constant-bus limit)
+__device__ __forceinline__ uint32_t writelane_u(uint32_t old, uint32_t val, int lane) {
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane));
+    return old;
+}
+
+// value of a lane-indexed-by-row register pair at (uniform) row s
+template <int NRSEG>
+__device__ __forceinline__ uint32_t read_row(const uint32_t (&r)[NRSEG], int s) {
+    uint32_t v = readlane_u(r[0], s & 63);
+    if (NRSEG > 1) {
+        const uint32_t h = readlane_u(r[NRSEG - 1], s & 63);
+        if (s >= 64) v = h;
+    }
+    return v;
+}
+// per-lane gather from a lane-indexed-by-row register pair (row differs per lane)
+template <int NRSEG>
+__device__ __forceinline__ uint32_t gather_row(const uint32_t (&r)[NRSEG], uint32_t row) {
+    uint32_t v = bperm((row & 63u) << 2, r[0]);
+    if (NRSEG > 1) {
+        const uint32_t h = bperm((row & 63u) << 2, r[NRSEG - 1]);
+        if (row >= 64u) v = h;
+    }
+    return v;
+}
+
+// ---- table-type dependent pieces of train_net's arithmetic (thrl_device.h td_value) ------------
+// Operands of one 32-transition block in "step layout": lane 32h + t = agent h, transition t.
+// float : c1 = fma(alpha, reward, (1-alpha)*old_value) -- everything of the target that does not
+//         depend on the live next_max; the pass then executes ONE fma (thrl_device.h, float32 form).
+// double: the reference's four separately rounded operations need reward and (1-alpha)*old_value.
+template <typename QT> struct BlockOps;
+template <> struct BlockOps<float> {
+    unsigned c1;
+    __device__ __forceinline__ void permute(unsigned sel) { c1 = bperm(sel, c1); }
+    __device__ __forceinline__ float value(float nm, float alpha_gamma, float, float) const {
+        return __fmaf_rn(alpha_gamma, nm, __builtin_bit_cast(float, c1));
+    }
+};
+template <> struct BlockOps<double> {
+    unsigned r_lo, r_hi, t4_lo, t4_hi;
+    __device__ __forceinline__ void permute(unsigned sel) {
+        r_lo = bperm(sel, r_lo); r_hi = bperm(sel, r_hi); t4_lo = bperm(sel, t4_lo); t4_hi = bperm(sel, t4_hi);
+    }
+    __device__ __forceinline__ double value(double nm, double, double alpha, double gamma) const {
+        const double re = __hiloint2double((int)r_hi, (int)r_lo), t4 = __hiloint2double((int)t4_hi, (int)t4_lo);
+        const double t2 = __dadd_rn(re, __dmul_rn(gamma, nm));                 // agents.py:73
+        return __dadd_rn(t4, __dmul_rn(alpha, t2));                           // agents.py:72,74
+    }
+};
+// (1-alpha)*old_value of both agents for the 64 transitions of a segment, halves packed per 32
+template <typename QT> struct Snapshot;
+template <> struct Snapshot<float> {
+    v2u t4;
+    __device__ __forceinline__ void set(float oma0, float ov0, float oma1, float ov1) {
+        t4 = pack_halves(__builtin_bit_cast(unsigned, __fmul_rn(oma0, ov0)), __builtin_bit_cast(unsigned, __fmul_rn(oma1, ov1)));
+    }
+};
+template <> struct Snapshot<double> {
+    v2u lo, hi;
+    __device__ __forceinline__ void set(double oma0, double ov0, double oma1, double ov1) {
+        const double x0 = __dmul_rn(oma0, ov0), x1 = __dmul_rn(oma1, ov1);
+        lo = pack_halves((unsigned)__double2loint(x0), (unsigned)__double2loint(x1));
+        hi = pack_halves((unsigned)__double2hiint(x0), (unsigned)__double2hiint(x1));
+    }
+};
+__device__ __forceinline__ BlockOps<float> make_ops(const Snapshot<float>& s, int k, double r0d, double r1d, float alpha_h) {
+    const v2u req = pack_halves(__builtin_bit_cast(unsigned, (float)r0d), __builtin_bit_cast(unsigned, (float)r1d));
+    BlockOps<float> o;
+    o.c1 = __builtin_bit_cast(unsigned, __fmaf_rn(alpha_h, __builtin_bit_cast(float, k ? req.y : req.x),
+                                                  __builtin_bit_cast(float, k ? s.t4.y : s.t4.x)));
+    return o;
+}
+__device__ __forceinline__ BlockOps<double> make_ops(const Snapshot<double>& s, int k, double r0d, double r1d, double) {
+    const v2u rl = pack_halves((unsigned)__double2loint(r0d), (unsigned)__double2loint(r1d));
+    const v2u rh = pack_halves((unsigned)__double2hiint(r0d), (unsigned)__double2hiint(r1d));
+    BlockOps<double> o;
+    o.r_lo = k ? rl.y : rl.x; o.r_hi = k ? rh.y : rh.x;
+    o.t4_lo = k ? s.lo.y : s.lo.x; o.t4_hi = k ? s.hi.y : s.hi.x;
+    return o;
+}
+// per-agent hyper-parameters in the table's arithmetic type
+template <typename QT> struct HP;
+template <> struct HP<float> {
+    static __device__ __forceinline__ float gamma(const AgentParams& p) { return p.gamma_f; }
+    static __device__ __forceinline__ float alpha(const AgentParams& p) { return p.alpha_f; }
+    static __device__ __forceinline__ float one_minus_alpha(const AgentParams& p) { return p.one_minus_alpha_f; }
+    static __device__ __forceinline__ float from_double(double x) { return (float)x; }
+    static __device__ __forceinline__ float product(float a, float g) { return __fmul_rn(a, g); }
+};
+template <> struct HP<double> {
+    static __device__ __forceinline__ double gamma(const AgentParams& p) { return p.gamma; }
+    static __device__ __forceinline__ double alpha(const AgentParams& p) { return p.alpha; }
+    static __device__ __forceinline__ double one_minus_alpha(const AgentParams& p) { return p.one_minus_alpha; }
+    static __device__ __forceinline__ double from_double(double x) { return x; }
+    static __device__ __forceinline__ double product(double, double) { return 0.0; }    // unused in float64 mode
+};
+
+// One 32-transition block of train_net's loop (agents.py:68-76), four transitions per pass.
+// RDN = ceil(A / 8) row reads per lane.
+//   P        (step layout, lane 4g of the segment): the four next-state rows of group g, 7 bits each,
+//            | cut bits << 28 (bit j-1: a new pass starts before transition j of the group)
+//   ops, wo  operands / LDS store address of transition 4*(lane&7) + ((lane>>3)&3) ("exec layout")
+template <typename QT, int RDN>
+__device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
+                                             const unsigned (&rd_base)[4], unsigned row_shift, unsigned my_step,
+                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma) {
+    for (int gi = 0; gi * 4 < nsub; gi++) {
+        const uint32_t sP = readlane_u(P, lane_base + gi * 4);
+        const int nv = min(4, nsub - gi * 4);
+        const unsigned rowoff = ((sP >> row_shift) & 0x7Fu) * row_bytes;
+        const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
+        int lo = 0;
+        do {
+            const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
+            QT m = lds_load<QT>(rd_base[0] + rowoff);
+#pragma unroll
+            for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(rd_base[i] + rowoff));
+            m = group8_allmax(m);
+            const QT val = ops.value(m, alpha_gamma, alpha, gamma);
+            if ((unsigned)(my_step - (unsigned)(gi * 4 + lo)) < (unsigned)(hi - lo)) lds_store<QT>(wo, val);
+            __builtin_amdgcn_wave_barrier();
+            lo = hi;
+        } while (lo < nv);
+    }
+}
+
+// LDS capacity allows 20 resident waves per CU for the headline window in float32, i.e. 5 per
+// SIMD: keep the register allocation at <= 96 VGPRs there (NSEG <= 2).  float64 tables are twice
+// the size (11 games per CU), so the register budget is relaxed there.
+// NOISE: environment noise (environments.py:28-31) handled per step (price not on the LUT);
+// its larger row window leaves room for fewer waves, so the register budget is relaxed.
+// SWEEP: per-game hyper-parameter arrays (thrl_buffers.sweep_*); compiled only together with NOISE
+// so the headline variant carries none of that state.
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP>
+__global__ void __launch_bounds__(1024)
+__attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
+k_wave_episodes(const WaveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int A = a.A, W = a.win_rows, T = a.T, lo = a.row_lo;
+    const WaveLut L = wave_lut_layout(A);
+
+    {   // stage the payoff LUT once per block
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lut_ns);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        for (int k = threadIdx.x; k < (a.lut_bytes >> 2); k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+    const unsigned short* lut_ns = reinterpret_cast<const unsigned short*>(smem + L.ns_off);   // play | train<<8
+    const double* __restrict__ lut_price = reinterpret_cast<const double*>(a.lut_ns + L.price_off);   // HBM/L2
+    const double* lut_aq = reinterpret_cast<const double*>(smem + L.aq_off);
+    const double* lut_sct = reinterpret_cast<const double*>(smem + L.sct_off);
+
+    QT* tab0 = reinterpret_cast<QT*>(smem + a.lut_bytes + (size_t)wib * a.game_lds_bytes);
+    QT* tab1 = tab0 + (W + 2) * A;
+    const int half = lane >> 5;
+    const unsigned tab0_off = lds_addr(tab0);        // absolute LDS byte addresses
+    const unsigned tab1_off = lds_addr(tab1);
+    // replay ("exec") layout of a 32-transition block: lane 32h + 8k + j  <->  agent h, transition 4j + k
+    const int kk = (lane >> 3) & 3, jj = lane & 7;
+    const unsigned perm_sel = (unsigned)((lane & 32) + 4 * jj + kk) << 2;      // bpermute source of this lane
+    const unsigned my_step = (unsigned)(4 * jj + kk);
+    const unsigned row_shift = (unsigned)(7 * kk);
+    const unsigned row_bytes = (unsigned)A * (unsigned)sizeof(QT);
+    unsigned rd_base[4];                                                     // column chunks jj, jj+8, ... (clamped)
+#pragma unroll
+    for (int i = 0; i < 4; i++) rd_base[i] = (half ? tab1_off : tab0_off) + (unsigned)sizeof(QT) * (unsigned)min(jj + 8 * i, A - 1);
+
+    const AgentParams& p0 = a.ag[0];
+    const AgentParams& p1 = a.ag[1];
+    const double inv_T_den = (double)T;
+
+    // lane ((e&15)*4+k): sum over this wave's games of episode-e log value k (e < 16 / e >= 16), as
+    // fixed-point integers: the games a wave gets are not deterministic, integer sums do not care
+    long long acc = 0, acc_hi = 0;
+    const double log_scale = (lane & 2) ? a.log_scale[1] : a.log_scale[0];
+    const int wave_gid = blockIdx.x * a.waves_per_block + wib;
+
+    // Games are handed out dynamically (one atomic per game): waves on less crowded CUs simply take
+    // more games, which measured 7-13 % faster than the static grid-stride assignment.
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(a.next_game, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= a.G) break;
+        const uint64_t gid = a.game_offset + (uint64_t)g;
+        QT* __restrict__ q0 = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride + p0.table_off;
+        QT* __restrict__ q1 = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride + p1.table_off;
+
+        // ---- per-game hyper-parameters (sweeps) or the config's scalars
+        QT gamma_h = half ? HP<QT>::gamma(p1) : HP<QT>::gamma(p0);
+        QT alpha_h = half ? HP<QT>::alpha(p1) : HP<QT>::alpha(p0);
+        QT oma0 = HP<QT>::one_minus_alpha(p0), oma1 = HP<QT>::one_minus_alpha(p1);
+        if (SWEEP && a.sw_gamma) gamma_h = HP<QT>::from_double(a.sw_gamma[(size_t)half * a.G + g]);
+        if (SWEEP && a.sw_alpha) {
+            alpha_h = HP<QT>::from_double(a.sw_alpha[(size_t)half * a.G + g]);
+            oma0 = HP<QT>::from_double(__dsub_rn(1.0, a.sw_alpha[g]));
+            oma1 = HP<QT>::from_double(__dsub_rn(1.0, a.sw_alpha[(size_t)a.G + g]));
+        }
+        double epsg0 = 0.0, epsg1 = 0.0;               // per-game epsilon (sweep mode)
+        const bool sw_eps_on = SWEEP && a.sw_eps != nullptr;
+        if (sw_eps_on) { epsg0 = a.sw_eps[g]; epsg1 = a.sw_eps[(size_t)a.G + g]; }
+        const QT ag_h = HP<QT>::product(alpha_h, gamma_h);   // float32: the only coefficient on the replay chain
+        const double eend0 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[g] : p0.eps_end;
+        const double eend1 = (SWEEP && a.sw_eps_end) ? a.sw_eps_end[(size_t)a.G + g] : p1.eps_end;
+        const double estep0 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[g] : p0.eps_step;
+        const double estep1 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[(size_t)a.G + g] : p1.eps_step;
+        const double noise_prob_g = (SWEEP && a.sw_noise_prob) ? a.sw_noise_prob[g] : a.env.noise_prob;
+
+        // ---- initial state -> local rows (window or spill)
+        const double price0 = a.state[g];
+        int sp = __builtin_amdgcn_readfirstlane(encode32(price0, p0));
+        int st = __builtin_amdgcn_readfirstlane(encode64(price0, p0));
+        sp = min(max(sp, 0), a.rows - 1);
+        st = min(max(st, 0), a.rows - 1);
+        int spill0 = -1, spill1 = -1, sp_l, st_l;
+        if (sp >= lo && sp < lo + W) sp_l = sp - lo; else { spill0 = sp; sp_l = W; }
+        if (st == sp) st_l = sp_l;
+        else if (st >= lo && st < lo + W) st_l = st - lo;
+        else { spill1 = st; st_l = W + 1; }
+
+        // ---- stream the table windows HBM -> LDS (contiguous, coalesced)
+        {
+            const QT* s0 = q0 + lo * A;
+            const QT* s1 = q1 + lo * A;
+            const int n = W * A;
+            // 8 loads per agent in flight before the first LDS write (one HBM latency per
+            // batch instead of one per 64 elements)
+            for (int k0 = 0; k0 < n; k0 += 512) {
+                QT v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = min(k0 + j * 64 + lane, n - 1);
+                    v0[j] = s0[k]; v1[j] = s1[k];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + j * 64 + lane;
+                    if (k < n) { tab0[k] = v0[j]; tab1[k] = v1[j]; }
+                }
+            }
+            if (spill0 >= 0 && lane < A) {
+                tab0[W * A + lane] = q0[spill0 * A + lane];
+                tab1[W * A + lane] = q1[spill0 * A + lane];
+            }
+            if (spill1 >= 0 && lane < A) {
+                tab0[(W + 1) * A + lane] = q0[spill1 * A + lane];
+                tab1[(W + 1) * A + lane] = q1[spill1 * A + lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        int s = sp_l | (st_l << 8);          // current state: play row | train row << 8
+        double last_price = price0;
+        for (int e = 0; e < a.n_episodes; e++) {
+            const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
+            const double eps0 = sw_eps_on ? epsg0 : a.eps[e][0], eps1 = sw_eps_on ? epsg1 : a.eps[e][1];
+
+            // ---- (a) greedy action of every local row, lane = row (the table is frozen
+            //          during play: agents.py only writes it in train_net), and the
+            //          greedy-greedy successor row of every row
+            uint32_t am0[NRSEG], am1[NRSEG], am0A[NRSEG], grow[NRSEG];
+            uint32_t am0A2[NRSEG], am1x2[NRSEG];      // byte offsets into the u16 LUT (x2), for the play loop
+#pragma unroll
+            for (int k = 0; k < NRSEG; k++) {
+                const int row = min(lane + 64 * k, W + 1);
+                const QT* r0 = tab0 + row * A;
+                const QT* r1 = tab1 + row * A;
+                QT b0 = r0[0], b1 = r1[0];
+                uint32_t i0 = 0, i1 = 0;
+#pragma unroll 4
+                for (int j = 1; j < A; j++) {
+                    const QT v0 = r0[j], v1 = r1[j];
+                    if (v0 > b0) { b0 = v0; i0 = j; }
+                    if (v1 > b1) { b1 = v1; i1 = j; }
+                }
+                am0[k] = i0; am1[k] = i1; am0A[k] = i0 * (uint32_t)A;
+                am0A2[k] = am0A[k] * 2u; am1x2[k] = i1 * 2u;
+                grow[k] = lut_ns[i0 * (uint32_t)A + i1];
+            }
+
+            // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
+            //      seq[seg] lane t = row in which step t was played.
+            uint32_t seq[NSEG], rwv[NSEG];
+            uint32_t kwv[NSEG];            // per step: flags | K << 8, K = (f0 ? c0*A : 0) + (f1 ? c1 : 0)
+            double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int n = min(64, T - seg * 64);
+                uint32_t rw;
+                nav[seg] = 0.0;
+                if (a.inj_u) {
+                    // parity mode: the reference's recorded draws, [E][T][2][G] (agents.py:81-82)
+                    const int tt = min(seg * 64 + lane, T - 1);
+                    const size_t k = (((size_t)e * T + tt) * 2) * (size_t)a.G + (size_t)g;
+                    const uint32_t ex0 = a.inj_u[k] < eps0 ? 1u : 0u;
+                    const uint32_t ex1 = a.inj_u[k + a.G] < eps1 ? 2u : 0u;
+                    const uint32_t c0 = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(A - 1));
+                    const uint32_t c1 = min((uint32_t)(uint8_t)a.inj_choice[k + a.G], (uint32_t)(A - 1));
+                    rw = ex0 | ex1 | (c0 << 8) | (c1 << 16);
+                } else {
+                    const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
+                    const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
+                    const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
+                    rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) | (__umulhi(x.w, (uint32_t)A) << 16);
+                }
+                if (NOISE) {               // environments.py:28-29, bit 2 of rw = noisy step
+                    double nu, na;
+                    if (a.inj_u) {
+                        const int tt = min(seg * 64 + lane, T - 1);
+                        const size_t k = ((size_t)e * T + tt) * (size_t)a.G + (size_t)g;
+                        nu = a.inj_noise_u[k]; na = a.inj_noise_a[k];
+                    } else {
+                        const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), kStreamNoise);
+                        nu = u01_32(xn.x);
+                        na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
+                    }
+                    if (nu < noise_prob_g) rw |= 4u;
+                    nav[seg] = na;
+                }
+                rwv[seg] = rw;
+                const uint32_t kw = (rw & 7u) |
+                    ((((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) + ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u)) << 8);
+                kwv[seg] = kw;
+                uint32_t sq = 0;
+                // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
+                // for every row r the next row if step t were played in r,
+                //   nsr_t[r] = LUT[a0][a1],  a_i = explore_i(t) ? choice_i(t) : argmax_i[r];
+                // it does not depend on the current state, so its LDS gathers overlap.
+                // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step.
+                for (int t0 = 0; t0 < n; t0 += 4) {
+                    uint32_t nsr[4][NRSEG];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t w = readlane_u(NOISE ? rw : kw, min(t0 + j, 63));
+                        if (NOISE && (w & 4u)) {
+                            // noisy step: the price is not on the LUT; evaluate it for every row
+                            const int tl = min(t0 + j, 63);
+                            const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nav[seg]), tl),
+                                                               __builtin_amdgcn_readlane(__double2loint(nav[seg]), tl));
+                            const uint32_t c0 = (w >> 8) & 0xFFu, c1 = (w >> 16) & 0xFFu;
+#pragma unroll
+                            for (int k = 0; k < NRSEG; k++) {
+                                const uint32_t a0r = (w & 1u) ? c0 : am0[k], a1r = (w & 2u) ? c1 : am1[k];
+                                const double Q = __dadd_rn(lut_aq[a0r], lut_aq[A + a1r]);
+                                double pr = __dsub_rn(na, __dmul_rn(a.env.b, Q));
+                                if (!(pr > 0.0)) pr = 0.0;
+                                const int r32 = min(max(encode32(pr, p0) - lo, 0), W - 1);
+                                const int r64 = min(max(encode64(pr, p0) - lo, 0), W - 1);
+                                nsr[j][k] = (uint32_t)(r32 | (r64 << 8));
+                            }
+                        } else if ((w & 3u) == 0u) {
+#pragma unroll
+                            for (int k = 0; k < NRSEG; k++) nsr[j][k] = grow[k];
+                        } else {
+                            if (NOISE) {
+                                const uint32_t c0A = ((w >> 8) & 0xFFu) * (uint32_t)A, c1 = (w >> 16) & 0xFFu;
+#pragma unroll
+                                for (int k = 0; k < NRSEG; k++) {
+                                    const uint32_t idx = ((w & 1u) ? c0A : am0A[k]) + ((w & 2u) ? c1 : am1[k]);
+                                    nsr[j][k] = lut_ns[idx];
+                                }
+                            } else {
+                                // idx = greedy part (masked by the not-exploring flags) + precomputed K
+                                const uint32_t nf0 = (w & 1u) ^ 1u, nf1 = ((w >> 1) & 1u) ^ 1u, K2 = (w >> 8) << 1;
+#pragma unroll
+                                for (int k = 0; k < NRSEG; k++) {
+                                    const uint32_t off = __umul24(am0A2[k], nf0) + __umul24(am1x2[k], nf1) + K2;
+                                    nsr[j][k] = *reinterpret_cast<const unsigned short*>(
+                                        reinterpret_cast<const unsigned char*>(lut_ns) + off);
+                                }
+                            }
+                        }
+                    }
+                    if (t0 + 4 <= n) {          // full group: no per-step bound checks on the chain
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            sq = writelane_u(sq, (uint32_t)s, t0 + j);
+                            s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (t0 + j < n) {
+                                sq = writelane_u(sq, (uint32_t)s, t0 + j);
+                                s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
+                            }
+                        }
+                    }
+                }
+                seq[seg] = sq;
+            }
+            const int s_end = s;
+
+            // ---- (d1) lane-parallel (lane = step): actions, old-value snapshot
+            //      (agents.py:67) for ALL steps before any TD write
+            uint32_t act[NSEG];            // a0 | a1<<8 | train_row<<16 | next_row<<24
+            Snapshot<QT> snap[NSEG];       // (1-alpha)*old_value, halves packed per 32 steps
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int tt = seg * 64 + lane;
+                const bool valid = tt < T;
+                const uint32_t my_s = seq[seg] & 0xFFu;              // row the step was played in
+                const uint32_t my_train = (seq[seg] >> 8) & 0xFFu;   // row train_net sees for that state
+                const uint32_t rw = rwv[seg];
+                // gather with ALL lanes active (a bpermute reads only from active lanes, and
+                // the source lane here is a table row, unrelated to this lane's step), then select
+                const uint32_t g0 = gather_row<NRSEG>(am0, my_s);
+                const uint32_t g1 = gather_row<NRSEG>(am1, my_s);
+                uint32_t a0 = (rw & 1u) ? ((rw >> 8) & 0xFFu) : g0;
+                uint32_t a1 = (rw & 2u) ? ((rw >> 16) & 0xFFu) : g1;
+                uint32_t nxt = (uint32_t)__shfl_down((int)seq[seg], 1, 64);
+                if (seg + 1 < NSEG) { if (lane == 63) nxt = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
+                const uint32_t ns = (tt + 1 < T) ? ((nxt >> 8) & 0xFFu) : ((uint32_t)s_end >> 8);
+                uint32_t srow = my_train;
+                if (!valid) { a0 = 0; a1 = 0; srow = 0; }
+                snap[seg].set(oma0, tab0[srow * A + a0], oma1, tab1[srow * A + a1]);
+                act[seg] = a0 | (a1 << 8) | (srow << 16) | (ns << 24);
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            double lr0 = 0.0, lr1 = 0.0, la0 = 0.0, la1 = 0.0;
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                // ---- (d2) rewards, LDS write addresses, logs, visit counters of this segment
+                const int tt = seg * 64 + lane;
+                const bool valid = tt < T;
+                const uint32_t a0 = act[seg] & 0xFFu, a1 = (act[seg] >> 8) & 0xFFu;
+                const uint32_t srow = (act[seg] >> 16) & 0xFFu;
+                double price = lut_price[a0 * (uint32_t)A + a1];
+                if (NOISE) {
+                    double pn = __dsub_rn(nav[seg], __dmul_rn(a.env.b, __dadd_rn(lut_aq[a0], lut_aq[A + a1])));
+                    if (!(pn > 0.0)) pn = 0.0;
+                    if (rwv[seg] & 4u) price = pn;
+                }
+                const double r0d = __dmul_rn(price, lut_aq[a0]);
+                const double r1d = __dmul_rn(price, lut_aq[A + a1]);
+                if (seg == NSEG - 1) {
+                    const int ll = T - 1 - seg * 64;       // lane of the episode's last step
+                    last_price = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(price), ll),
+                                                  __builtin_amdgcn_readlane(__double2loint(price), ll));
+                }
+                const v2u woq = pack_halves(tab0_off + (srow * A + a0) * (unsigned)sizeof(QT),
+                                            tab1_off + (srow * A + a1) * (unsigned)sizeof(QT));
+                if (valid) {
+                    lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
+                    la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
+                }
+                // visit counters (agents.py:76): the packed transition word goes to this wave's
+                // log (coalesced, L2-resident); the counts are built per game below
+                if (a.counter)
+                    a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + e) * NSEG + seg) * 64 + lane] =
+                        valid ? act[seg] : 0xFFFFFFFFu;
+
+                // ---- replay schedule of this segment's 16 groups of four transitions, lane-parallel.
+                //      Transition j may share a pass with an earlier transition i of its group unless it
+                //      reads the row i writes (live next_max, agents.py:71) or rewrites i's cell (:75).
+                uint32_t P;
+                {
+                    const uint32_t w = act[seg];
+                    const uint32_t b0 = dpp_mov32<0x00>(w), b1 = dpp_mov32<0x55>(w), b2 = dpp_mov32<0xAA>(w),
+                                   b3 = dpp_mov32<0xFF>(w);                       // quad broadcasts of positions 0..3
+                    const uint32_t qp = (uint32_t)lane & 3u;
+                    auto hz = [&](uint32_t bi, uint32_t i) -> uint32_t {
+                        const bool raw = (w >> 24) == ((bi >> 16) & 0xFFu);            // my next-state row == its written row
+                        const bool waw = ((w >> 16) & 0xFFu) == ((bi >> 16) & 0xFFu) &&
+                                         ((w & 0xFFu) == (bi & 0xFFu) || ((w >> 8) & 0xFFu) == ((bi >> 8) & 0xFFu));
+                        return (qp > i && (raw || waw)) ? 1u : 0u;
+                    };
+                    const uint32_t hzw = hz(b0, 0u) | (hz(b1, 1u) << 1) | (hz(b2, 2u) << 2);
+                    const uint32_t h1 = dpp_mov32<0x55>(hzw), h2 = dpp_mov32<0xAA>(hzw), h3 = dpp_mov32<0xFF>(hzw);
+                    const uint32_t c1 = h1 & 1u;
+                    const uint32_t c2 = ((h2 >> 1) & 1u) | ((c1 ^ 1u) & h2 & 1u);
+                    const uint32_t c3 = ((h3 >> 2) & 1u) | ((c2 ^ 1u) & (((h3 >> 1) & 1u) | ((c1 ^ 1u) & h3 & 1u)));
+                    P = (b0 >> 24) | ((b1 >> 24) << 7) | ((b2 >> 24) << 14) | ((b3 >> 24) << 21) |
+                        ((c1 | (c2 << 1) | (c3 << 2)) << 28);
+                }
+
+                // ---- (e) replay (agents.py:68-76): live next_max, writes in transition order
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
+                    if (nsub <= 0) break;
+                    BlockOps<QT> ops = make_ops(snap[seg], k, r0d, r1d, alpha_h);
+                    ops.permute(perm_sel);                                   // step layout -> exec layout
+                    const unsigned wo = bperm(perm_sel, k ? woq.y : woq.x);
+                    if (A > 24)
+                        replay_block<QT, 4>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
+                    else if (A > 16)
+                        replay_block<QT, 3>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
+                    else
+                        replay_block<QT, 2>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
+                }
+            }
+
+            // ---- (f) per-episode log sums of this game into the wave accumulator:
+            //      lane L gets the wave total of quantity L&3 = (reward0, reward1, action0, action1)
+            {
+                double v = wave_sum4(lr0, lr1, la0, la1, lane);
+                if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
+                const long long vq = __double2ll_rn(__dmul_rn(v, log_scale));
+                if ((lane >> 2) == (e & 15)) { if (e < 16) acc += vq; else acc_hi += vq; }
+            }
+            // epsilon decays after every train_net call (agents.py:78)
+            if (SWEEP) {
+                epsg0 = __dadd_rn(eend0, __dmul_rn(__dsub_rn(epsg0, eend0), estep0));
+                epsg1 = __dadd_rn(eend1, __dmul_rn(__dsub_rn(epsg1, eend1), estep1));
+            }
+        }
+
+        // ---- stream the windows back LDS -> HBM, store the env state
+        {
+            QT* d0 = q0 + lo * A;
+            QT* d1 = q1 + lo * A;
+            const int n = W * A;
+            for (int k = lane; k < n; k += 64) { d0[k] = tab0[k]; d1[k] = tab1[k]; }
+            if (spill0 >= 0 && lane < A) {
+                q0[spill0 * A + lane] = tab0[W * A + lane];
+                q1[spill0 * A + lane] = tab1[W * A + lane];
+            }
+            if (spill1 >= 0 && lane < A) {
+                q0[spill1 * A + lane] = tab0[(W + 1) * A + lane];
+                q1[spill1 * A + lane] = tab1[(W + 1) * A + lane];
+            }
+            if (lane == 0 && a.n_episodes > 0) a.state[g] = last_price;
+            if (lane == 0 && sw_eps_on) { a.sw_eps[g] = epsg0; a.sw_eps[(size_t)a.G + g] = epsg1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- visit counters of this game (agents.py:76).  The tables are back in HBM, so
+        //      the wave's LDS region is free: build the launch's visit histogram there
+        //      (u16 pairs in dwords, ds_add_u32; E*T <= 32*256 < 65536 so no carry) from the
+        //      transition log, then apply it to the counter window with plain coalesced
+        //      read-add-write -- this game's counters belong to this wave alone, so no
+        //      global atomics are needed (2e9 scattered atomics per launch were a 70 ms floor).
+        if (a.counter) {
+            const int cells = (W + 2) * A;                       // per agent
+            const int hw = (cells + 1) >> 1;                     // dwords per agent
+            // may_alias: the histogram overlays the tables (no type-based reordering)
+            typedef unsigned __attribute__((may_alias)) hist_u32;
+            hist_u32* hist = reinterpret_cast<hist_u32*>(tab0);   // 2*hw dwords <= 2*cells table elements
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (int k = lane; k < 2 * hw; k += 64) hist[k] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            // log read-back: 4 episodes' loads in flight at a time (sc1 = L2-served: the wave
+            // reads what it stored itself)
+            for (int e0 = 0; e0 < a.n_episodes; e0 += 4) {
+                unsigned w[4][NSEG];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int seg = 0; seg < NSEG; seg++)
+                        w[j][seg] = __hip_atomic_load(
+                            &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + min(e0 + j, a.n_episodes - 1)) * NSEG + seg) * 64 + lane],
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int seg = 0; seg < NSEG; seg++) {
+                        const unsigned ww = w[j][seg];
+                        if (e0 + j < a.n_episodes && ww != 0xFFFFFFFFu) {
+                            const unsigned srow = (ww >> 16) & 0xFFu;
+                            const unsigned c0 = srow * (unsigned)A + (ww & 0xFFu);
+                            const unsigned c1 = srow * (unsigned)A + ((ww >> 8) & 0xFFu);
+                            __hip_atomic_fetch_add(&hist[c0 >> 1], 1u << ((c0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_add(&hist[hw + (c1 >> 1)], 1u << ((c1 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // apply: window rows are contiguous in HBM, so cell k of the window is element
+            // lo*A + k of the agent's table (no row/column split); spill rows separately
+            int32_t* cw0 = a.counter + (int64_t)g * a.stride + p0.table_off;
+            int32_t* cw1 = a.counter + (int64_t)g * a.stride + p1.table_off;
+            const int nwin = W * A;
+            for (int k = lane; k < nwin; k += 64) {
+                const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
+                if (n0) cw0[lo * A + k] += (int32_t)n0;
+                if (n1) cw1[lo * A + k] += (int32_t)n1;
+            }
+            if (lane < 2 * A) {
+                const int which = lane >= A, col = lane - which * A;
+                const int grow_ = which ? spill1 : spill0;
+                const int k = nwin + lane;
+                if (grow_ >= 0) {
+                    const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                    const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
+                    if (n0) cw0[grow_ * A + col] += (int32_t)n0;
+                    if (n1) cw1[grow_ * A + col] += (int32_t)n1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    a.partial[(size_t)wave_gid * 128 + lane] = acc;
+    a.partial[(size_t)wave_gid * 128 + 64 + lane] = acc_hi;
+}
+
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP>
+static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    auto kern = k_wave_episodes<QT, NSEG, NRSEG, NOISE, SWEEP>;
+    if (lds > 64 * 1024) {                       // beyond the default dynamic-LDS limit (float64 tables: one block per CU)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+template <typename QT, bool NOISE, bool SWEEP>
+static int launch_wave_n(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    const int nseg = (a.T + 63) / 64;
+    const int nrseg = (a.win_rows + 2 + 63) / 64;
+    if (nrseg == 1) {
+        switch (nseg) {
+            case 1: return launch_wave_t<QT, 1, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+        }
+    } else if (nrseg == 2) {
+        switch (nseg) {
+            case 1: return launch_wave_t<QT, 1, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+        }
+    }
+    return -1;
+}
+
+}  // namespace thrl

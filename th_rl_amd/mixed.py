@@ -30,7 +30,7 @@ NN_DEFAULTS = dict(states=4, actions=2, action_range=[0, 1], gamma=0.98, capacit
 
 
 class MixedGameBatch:
-    def __init__(self, config, n_games=1, device="cuda:0", dtype="float32", seed=0, game_offset=0):
+    def __init__(self, config, n_games=1, device="cuda:0", dtype="float32", seed=0, game_offset=0, sweep=None):
         self.L = _lib.load()
         torch = _torch()
         self.device = _require_gpu(device)
@@ -104,6 +104,34 @@ class MixedGameBatch:
         self.episode = 0
         self.initialized = False
         self._fused_launched = False         # True once a fused launch has advanced the state
+        self.sweep = {}
+        if sweep:
+            self.set_sweep(sweep)
+
+    # ------------------------------------------------------------------ sweeps
+    SWEEP_KEYS = ("gamma", "alpha", "eps_end", "eps_step", "eps", "noise_prob", "entropy")
+
+    def set_sweep(self, sweep):
+        """Per-game hyper-parameters -- the reference's config sweep (one process per config and run,
+        main.py:13-21) as ONE batch.  dict of arrays [N, G] (or [G]: the same for every agent) for
+        gamma / alpha / eps (starting epsilon) / eps_end / eps_step / entropy, and [G] for noise_prob.
+        A row applies to whatever agent sits in that slot: gamma is QTable.gamma or the neural agent's
+        discount, alpha / eps* are read for QTable agents only, entropy for neural agents only.  Absent
+        keys keep the config's scalar.  Call before init_tables() when gamma is swept."""
+        torch = _torch()
+        for k, v in sweep.items():
+            if k not in self.SWEEP_KEYS:
+                raise ThrlError("unknown sweep key %r (known: %s)" % (k, ", ".join(self.SWEEP_KEYS)))
+            a = np.asarray(v, np.float64)
+            a = a.reshape(self.G) if k == "noise_prob" else np.broadcast_to(a.reshape(-1, self.G), (self.N, self.G)).copy()
+            self.sweep[k] = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if ("eps_end" in self.sweep or "eps_step" in self.sweep) and "eps" not in self.sweep:
+            start = np.repeat(np.asarray(self.eps[:self.N], np.float64)[:, None], self.G, axis=1)
+            self.sweep["eps"] = torch.from_numpy(start).to(self.device)
+        for i, rb in self.nn.items():            # the neural agents' own sweeps go to their update kernels
+            rb.set_sweep(gamma=self.sweep["gamma"][i] if "gamma" in self.sweep else None,
+                         entropy=self.sweep["entropy"][i] if "entropy" in self.sweep else None)
+        return self
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -117,7 +145,8 @@ class MixedGameBatch:
         torch = _torch()
         with torch.cuda.device(self.device):
             _lib.check(self.L.thrl_qtable_init(ctypes.byref(self.cfg), self._p(self.q), self._p(self.counter),
-                                               self._p(self.state), self.seed, self.game_offset, self._stream()),
+                                               self._p(self.state), self.seed, self.game_offset,
+                                               self._p(self.sweep.get("gamma")), self._stream()),
                        "thrl_qtable_init")
         for rb in self.nn.values():
             rb.init()
@@ -213,6 +242,7 @@ class MixedGameBatch:
                     eps=[float(x) for x in self.eps], count=[int(x) for x in self.count],
                     q=self.q.cpu(), counter=self.counter.cpu(), state=self.state.cpu(),
                     buffers=[{k: v.cpu() for k, v in b.items()} for b in self.buf],
+                    sweep={k: v.cpu() for k, v in self.sweep.items()},
                     nn={int(i): dict(params=rb.params.cpu(), adam_m=rb.adam_m.cpu(), adam_v=rb.adam_v.cpu(),
                                      step=int(rb.step)) for i, rb in self.nn.items()})
 
@@ -231,6 +261,8 @@ class MixedGameBatch:
         for b, src in zip(self.buf, sd["buffers"]):
             for k in b:
                 b[k].copy_(src[k])
+        if sd.get("sweep"):
+            self.set_sweep({k: v.numpy() for k, v in sd["sweep"].items()})
         for i, rb in self.nn.items():
             src = sd["nn"][int(i)]
             rb.params.copy_(src["params"]); rb.adam_m.copy_(src["adam_m"]); rb.adam_v.copy_(src["adam_v"])
@@ -323,6 +355,9 @@ class MixedGameBatch:
                     if self._scratch[i] is not None:
                         mx.buf_scratch[i] = self._scratch[i].data_ptr()
                     mx.buf_len[i], mx.min_memory[i], mx.count[i] = self.buf_len[i], self.min_memory[i], self.count[i]
+                for key in ("gamma", "alpha", "eps_end", "eps_step", "eps", "noise_prob"):
+                    if key in self.sweep:
+                        setattr(mx, "sweep_" + key, self.sweep[key].data_ptr())
                 r = _lib.Run()
                 r.seed, r.game_offset, r.first_episode, r.n_episodes = self.seed, self.game_offset, self.episode, k
                 for i in range(N):
@@ -355,6 +390,9 @@ class MixedGameBatch:
         if not self.initialized:
             raise ThrlError("MixedGameBatch: call init_tables() or set_tables() first")
         E, N, G, T = int(n_episodes), self.N, self.G, self.T
+        if self.sweep:
+            raise ThrlError("per-game sweeps run on the fused path (run(fused=True)); the operator loop takes the "
+                            "config's scalars only")
         cfg = ctypes.byref(self.cfg)
         L = self.L
         noise = self.cfg.noise_prob > 0

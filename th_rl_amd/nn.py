@@ -30,6 +30,16 @@ class ReinforceBatch:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
         self.step = 0
+        self.gamma_g = self.entropy_g = None      # per-game sweeps (device float64 [G]) or None
+
+    def set_sweep(self, gamma=None, entropy=None):
+        """Per-game gamma / entropy coefficient (arrays of length G): a config sweep as one batch."""
+        torch = _torch()
+        if gamma is not None:
+            self.gamma_g = self._dev(np.asarray(gamma, np.float64).reshape(self.G), torch.float64)
+        if entropy is not None:
+            self.entropy_g = self._dev(np.asarray(entropy, np.float64).reshape(self.G), torch.float64)
+        return self
 
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
@@ -83,6 +93,7 @@ class ReinforceBatch:
             _lib.check(self.L.thrl_nn_reinforce_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
                                                       self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a),
                                                       self._p(d_r), self.gamma, self.entropy, self.lr,
+                                                      self._p(self.gamma_g), self._p(self.entropy_g),
                                                       self._p(grad), self._stream()), "thrl_nn_reinforce_train")
             torch.cuda.synchronize(self.device)
         self.step += 1
@@ -108,8 +119,8 @@ class ActorCriticBatch(ReinforceBatch):
             grad = torch.zeros_like(self.params) if want_grad else None
             _lib.check(self.L.thrl_ac_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
                                             self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a), self._p(d_r),
-                                            self._p(d_n), self.gamma, self.entropy, self.lr, self._p(grad),
-                                            self._stream()), "thrl_ac_train")
+                                            self._p(d_n), self.gamma, self.entropy, self.lr, self._p(self.gamma_g),
+                                            self._p(self.entropy_g), self._p(grad), self._stream()), "thrl_ac_train")
             torch.cuda.synchronize(self.device)
         self.step += 1
         return grad
@@ -134,7 +145,9 @@ class CACBatch:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
         self.step = 0
+        self.gamma_g = self.entropy_g = None
 
+    set_sweep = ReinforceBatch.set_sweep
     _stream = ReinforceBatch._stream
     _p = staticmethod(ReinforceBatch._p)
     _dev = ReinforceBatch._dev
@@ -175,7 +188,8 @@ class CACBatch:
             grad = torch.zeros_like(self.params) if want_grad else None
             _lib.check(self.L.thrl_cac_train(self.G, self._p(self.params), self._p(self.adam_m), self._p(self.adam_v),
                                              self.step, n, self._p(d_p), self._p(d_a), self._p(d_r), self._p(d_n),
-                                             self.gamma, self.entropy, self.lr, self._p(grad), self._stream()),
+                                             self.gamma, self.entropy, self.lr, self._p(self.gamma_g), self._p(self.entropy_g),
+                                             self._p(grad), self._stream()),
                        "thrl_cac_train")
             torch.cuda.synchronize(self.device)
         self.step += 1

@@ -16,7 +16,9 @@ kernels).  The JSON schema is the reference's; the optional extra keys in the
                  "resume": null,     # path of a batch.pt written by an earlier run: continue it
                  "sweep": null}      # per-game hyper-parameters, e.g. {"gamma": [0.35, 0.95, ...]}: arrays of
                                      # length n_games (or [agent][game]) for gamma / alpha / eps / eps_end /
-                                     # eps_step / noise_prob -- a config sweep as ONE batched run
+                                     # eps_step / noise_prob (+ entropy for neural agents) -- a config sweep
+                                     # (main.py:13-21: one process per config and run) as ONE batched run,
+                                     # for all-QTable games and for games with neural agents alike
 
 n_games == 1: tables come from the constructed agents (numpy's global RNG, exactly where
 the reference draws them) and the run is float64.  n_games > 1: every game's tables and
@@ -88,15 +90,19 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     names = [a["name"] for a in config["agents"]]
 
     resume = training.get("resume", None)
-    # All-QTable games the LDS-resident wave kernel cannot take (float64 tables -- the default for one
-    # game --, other than 2 agents, per-agent grids, T < min_memory) run one wavefront per game through
-    # the mixed-agent episode kernel while the batch is small: 4.7x (1 game) to 1.3x (16,384 games) the
-    # one-thread-per-game generic kernel, same bits.  Explicit "kernel" / "sweep" keys keep GameBatch.
+    # Small all-QTable batches in float64 (the default for ONE game = the reference's own use), and those
+    # the LDS-resident wave kernel cannot take (other than 2 agents, per-agent grids, T < min_memory), run one
+    # wavefront per game through the mixed-agent episode kernel: it keeps train_one's per-step log arithmetic
+    # (rewards_log += reward / max_steps, trainer.py:65), so a single game's log.csv is the reference's to the
+    # last bit, and it is 4.7x (1 game) to 1.3x (16,384 games) faster than the one-thread-per-game generic
+    # kernel, same bits.  Larger float64 batches use the wave kernel's float64 variant (tables, counters,
+    # epsilon, state identical; logs to 1e-12).  Explicit "kernel" / "sweep" keys keep GameBatch.
     small_tabular = False
     if all_tabular and "kernel" not in training and not training.get("sweep") and n_games <= 16384 and not resume_is_gamebatch(resume):
         import ctypes
         cfg_probe, _ = _lib.cfg_from_config(config, n_games, {"float32": 0, "float64": 1}[str(dtype)])
-        small_tabular = _lib.load().thrl_select_kernel(ctypes.byref(cfg_probe), 0) == _lib.KERNEL_GENERIC
+        small_tabular = (str(dtype) == "float64"
+                         or _lib.load().thrl_select_kernel(ctypes.byref(cfg_probe), 0) == _lib.KERNEL_GENERIC)
     if all_tabular and not small_tabular:
         batch = GameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
                           seed=seed, game_offset=int(training.get("game_offset", 0)),
@@ -105,7 +111,8 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         # games with neural agents: fused episode kernel + batched network updates (mixed.py)
         from th_rl_amd.mixed import MixedGameBatch
         batch = MixedGameBatch(config, n_games=n_games, device=training.get("device", "cuda:0"), dtype=dtype,
-                               seed=seed, game_offset=int(training.get("game_offset", 0)))
+                               seed=seed, game_offset=int(training.get("game_offset", 0)),
+                               sweep=training.get("sweep", None))
     if resume:
         batch.load(resume)                              # tables, counters, state, epsilon, episode index
     elif n_games == 1 and not training.get("philox_init", False):
