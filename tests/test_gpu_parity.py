@@ -393,7 +393,7 @@ def test_per_game_sweeps_vs_oracle():
     assert o1["kernel"] == "wave"
     cfg, eps = O.cfg_from_config(config, G, 0)
     q = q0.copy(); c = np.zeros(q.shape, np.int32); s = s0.copy(); mem = O.Memory(cfg)
-    osw = {k: np.ascontiguousarray(np.asarray(v, np.float64)) for k, v in sweep.items()}
+    osw = {k: np.array(v, np.float64) for k, v in sweep.items()}          # copies: the oracle updates eps in place
     oo1 = O.episodes(cfg, q, c, s, eps, mem, E, seed=21, sweep=osw)
     oo2 = O.episodes(cfg, q, c, s, eps, mem, 3, seed=21, first_episode=E, sweep=osw)
     assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
@@ -438,7 +438,7 @@ def test_generic_kernel_sweeps_vs_oracle():
         assert out["kernel"] == "generic"
         cfg, eps0 = O.cfg_from_config(config, n_games=G, q_dtype=1 if dtype == "float64" else 0)
         q, st, cn = q0.copy(), s0.copy(), np.zeros(q0.shape, np.int32)
-        osw = {k: np.ascontiguousarray(np.asarray(v, np.float64)) for k, v in sweep.items()}
+        osw = {k: np.array(v, np.float64) for k, v in sweep.items()}      # copies: the oracle updates eps in place
         O.episodes(cfg, q, cn, st, eps0, O.Memory(cfg), E, seed=31, sweep=osw)
         assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), cn)
         assert np.array_equal(gb.states_numpy(), st)

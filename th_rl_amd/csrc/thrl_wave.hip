@@ -21,7 +21,6 @@ __global__ void __launch_bounds__(256) k_wave_lut(const WaveArgs a, unsigned cha
         // in the low byte, train row (float64 encode, agents.py:62,66) in the high byte
         reinterpret_cast<unsigned short*>(out + L.ns_off)[idx] =
             (unsigned short)((encode32(price, a.ag[0]) - a.row_lo) | ((encode64(price, a.ag[0]) - a.row_lo) << 8));
-        reinterpret_cast<double*>(out + L.price_off)[idx] = price;
     }
     if (idx < 2 * A) {
         const int i = idx / A, k = idx - i * A;

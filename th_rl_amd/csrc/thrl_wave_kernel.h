@@ -146,6 +146,30 @@ __device__ __forceinline__ uint32_t writelane_u(uint32_t old, uint32_t val, int 
     return old;
 }
 
+// lo16(x) + hi16(x) in one VALU instruction (sub-dword operand selects)
+__device__ __forceinline__ uint32_t halves_sum(uint32_t x) {
+    uint32_t y;
+    asm("v_add_u32_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// One step of the play chain for a one-register row table: lane t of `sq` <- s (the state step t is
+// played in), then s <- nsr[s & 63].  Hand-placed wait states (hipcc does not look inside asm):
+// a v_readlane whose lane select was written by a VALU (the previous step's v_readlane) needs 4 wait
+// states -- previous v_writelane + s_nop 1 + s_mov = 4 (FIRST: nothing is known about the instruction
+// before, so s_nop 2 + s_mov) -- and v_writelane needs 1 after the s_mov of M0 (the v_readlane).
+template <bool FIRST>
+__device__ __forceinline__ void chain_step(uint32_t& sq, int& s, uint32_t nsr, int t) {
+    int s_new;
+    if (FIRST)
+        asm volatile("s_nop 2\n\ts_mov_b32 m0, %4\n\tv_readlane_b32 %1, %3, %2\n\tv_writelane_b32 %0, %2, m0"
+                     : "+v"(sq), "=&s"(s_new) : "s"(s), "v"(nsr), "s"(t));
+    else
+        asm volatile("s_nop 1\n\ts_mov_b32 m0, %4\n\tv_readlane_b32 %1, %3, %2\n\tv_writelane_b32 %0, %2, m0"
+                     : "+v"(sq), "=&s"(s_new) : "s"(s), "v"(nsr), "s"(t));
+    s = s_new;
+}
+
 // value of a lane-indexed-by-row register pair at (uniform) row s
 template <int NRSEG>
 __device__ __forceinline__ uint32_t read_row(const uint32_t (&r)[NRSEG], int s) {
@@ -291,8 +315,7 @@ k_wave_episodes(const WaveArgs a) {
         for (int k = threadIdx.x; k < (a.lut_bytes >> 2); k += blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
-    const unsigned short* lut_ns = reinterpret_cast<const unsigned short*>(smem + L.ns_off);   // play | train<<8
-    const double* __restrict__ lut_price = reinterpret_cast<const double*>(a.lut_ns + L.price_off);   // HBM/L2
+    const unsigned lut_ns_lds = lds_addr(smem + L.ns_off);                            // u16 [A*A]: play row | train row << 8
     const double* lut_aq = reinterpret_cast<const double*>(smem + L.aq_off);
     const double* lut_sct = reinterpret_cast<const double*>(smem + L.sct_off);
 
@@ -323,14 +346,17 @@ k_wave_episodes(const WaveArgs a) {
 
     // Games are handed out dynamically (one atomic per game): waves on less crowded CUs simply take
     // more games, which measured 7-13 % faster than the static grid-stride assignment.
+    // The NEXT game's id is claimed when a game starts, so the atomic's round trip is off the path.
+    int g_claim = 0;
+    if (lane == 0) g_claim = atomicAdd(a.next_game, 1);
     for (;;) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(a.next_game, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
+        const int g = __builtin_amdgcn_readfirstlane(g_claim);
         if (g >= a.G) break;
+        if (lane == 0) g_claim = atomicAdd(a.next_game, 1);
         const uint64_t gid = a.game_offset + (uint64_t)g;
         QT* __restrict__ q0 = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride + p0.table_off;
         QT* __restrict__ q1 = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride + p1.table_off;
+        const double price0 = a.state[g];              // issued ahead of the table stream, used after it
 
         // ---- per-game hyper-parameters (sweeps) or the config's scalars
         QT gamma_h = half ? HP<QT>::gamma(p1) : HP<QT>::gamma(p0);
@@ -352,18 +378,6 @@ k_wave_episodes(const WaveArgs a) {
         const double estep1 = (SWEEP && a.sw_eps_step) ? a.sw_eps_step[(size_t)a.G + g] : p1.eps_step;
         const double noise_prob_g = (SWEEP && a.sw_noise_prob) ? a.sw_noise_prob[g] : a.env.noise_prob;
 
-        // ---- initial state -> local rows (window or spill)
-        const double price0 = a.state[g];
-        int sp = __builtin_amdgcn_readfirstlane(encode32(price0, p0));
-        int st = __builtin_amdgcn_readfirstlane(encode64(price0, p0));
-        sp = min(max(sp, 0), a.rows - 1);
-        st = min(max(st, 0), a.rows - 1);
-        int spill0 = -1, spill1 = -1, sp_l, st_l;
-        if (sp >= lo && sp < lo + W) sp_l = sp - lo; else { spill0 = sp; sp_l = W; }
-        if (st == sp) st_l = sp_l;
-        else if (st >= lo && st < lo + W) st_l = st - lo;
-        else { spill1 = st; st_l = W + 1; }
-
         // ---- stream the table windows HBM -> LDS (contiguous, coalesced)
         {
             const QT* s0 = q0 + lo * A;
@@ -384,6 +398,19 @@ k_wave_episodes(const WaveArgs a) {
                     if (k < n) { tab0[k] = v0[j]; tab1[k] = v1[j]; }
                 }
             }
+        }
+        // ---- initial state -> local rows (window or spill)
+        int sp = __builtin_amdgcn_readfirstlane(encode32(price0, p0));
+        int st = __builtin_amdgcn_readfirstlane(encode64(price0, p0));
+        sp = min(max(sp, 0), a.rows - 1);
+        st = min(max(st, 0), a.rows - 1);
+        int spill0 = -1, spill1 = -1, sp_l, st_l;
+        if (sp >= lo && sp < lo + W) sp_l = sp - lo; else { spill0 = sp; sp_l = W; }
+        if (st == sp) st_l = sp_l;
+        else if (st >= lo && st < lo + W) st_l = st - lo;
+        else { spill1 = st; st_l = W + 1; }
+
+        {
             if (spill0 >= 0 && lane < A) {
                 tab0[W * A + lane] = q0[spill0 * A + lane];
                 tab1[W * A + lane] = q1[spill0 * A + lane];
@@ -402,10 +429,10 @@ k_wave_episodes(const WaveArgs a) {
             const double eps0 = sw_eps_on ? epsg0 : a.eps[e][0], eps1 = sw_eps_on ? epsg1 : a.eps[e][1];
 
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
-            //          during play: agents.py only writes it in train_net), and the
-            //          greedy-greedy successor row of every row
-            uint32_t am0[NRSEG], am1[NRSEG], am0A[NRSEG], grow[NRSEG];
-            uint32_t am0A2[NRSEG], am1x2[NRSEG];      // byte offsets into the u16 LUT (x2), for the play loop
+            //          during play: agents.py only writes it in train_net).  R packs the two
+            //          greedy byte offsets into the u16 payoff LUT: agent 0's (a0*A*2) in the low
+            //          half, agent 1's (a1*2) in the high half.
+            uint32_t am0[NRSEG], am1[NRSEG], R[NRSEG];
 #pragma unroll
             for (int k = 0; k < NRSEG; k++) {
                 const int row = min(lane + 64 * k, W + 1);
@@ -419,15 +446,13 @@ k_wave_episodes(const WaveArgs a) {
                     if (v0 > b0) { b0 = v0; i0 = j; }
                     if (v1 > b1) { b1 = v1; i1 = j; }
                 }
-                am0[k] = i0; am1[k] = i1; am0A[k] = i0 * (uint32_t)A;
-                am0A2[k] = am0A[k] * 2u; am1x2[k] = i1 * 2u;
-                grow[k] = lut_ns[i0 * (uint32_t)A + i1];
+                am0[k] = i0; am1[k] = i1;
+                R[k] = (i0 * (uint32_t)A * 2u) | (i1 << 17);
             }
 
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
             uint32_t seq[NSEG], rwv[NSEG];
-            uint32_t kwv[NSEG];            // per step: flags | K << 8, K = (f0 ? c0*A : 0) + (f1 ? c1 : 0)
             double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
@@ -464,23 +489,22 @@ k_wave_episodes(const WaveArgs a) {
                     nav[seg] = na;
                 }
                 rwv[seg] = rw;
-                const uint32_t kw = (rw & 7u) |
-                    ((((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) + ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u)) << 8);
-                kwv[seg] = kw;
-                uint32_t sq = 0;
-                // Steps are taken 4 at a time.  Phase 1 (off the serial chain, lane = ROW):
-                // for every row r the next row if step t were played in r,
-                //   nsr_t[r] = LUT[a0][a1],  a_i = explore_i(t) ? choice_i(t) : argmax_i[r];
-                // it does not depend on the current state, so its LDS gathers overlap.
-                // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step.
-                for (int t0 = 0; t0 < n; t0 += 4) {
-                    uint32_t nsr[4][NRSEG];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t w = readlane_u(NOISE ? rw : kw, min(t0 + j, 63));
-                        if (NOISE && (w & 4u)) {
+                // Per step (lane = step), what turns the rows' greedy offsets R into the LUT address of
+                // "the next row if this step were played in row r":
+                //   Mv keeps agent i's half of R iff agent i does NOT explore in this step,
+                //   Kv = LUT base + 2 * (explore0 ? c0*A : 0) + 2 * (explore1 ? c1 : 0)
+                // so address(r) = lo16(R[r] & Mv) + hi16(R[r] & Mv) + Kv: no scalar control per step.
+                const uint32_t Mv = ((rw & 1u) ? 0u : 0xFFFFu) | ((rw & 2u) ? 0u : 0xFFFF0000u);
+                const uint32_t Kv = lut_ns_lds + 2u * (((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) +
+                                                      ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u));
+                // Phase 1 (off the serial chain, lane = ROW): nsr_t[r] for one step; its LDS gather does
+                // not depend on the current state.
+                auto build = [&](int t, uint32_t (&out)[NRSEG]) {
+                    const int tl = t;            // < 64: only groups that start below n <= 64 are built
+                    if (NOISE) {
+                        const uint32_t w = readlane_u(rw, tl);
+                        if (w & 4u) {
                             // noisy step: the price is not on the LUT; evaluate it for every row
-                            const int tl = min(t0 + j, 63);
                             const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nav[seg]), tl),
                                                                __builtin_amdgcn_readlane(__double2loint(nav[seg]), tl));
                             const uint32_t c0 = (w >> 8) & 0xFFu, c1 = (w >> 16) & 0xFFu;
@@ -492,46 +516,54 @@ k_wave_episodes(const WaveArgs a) {
                                 if (!(pr > 0.0)) pr = 0.0;
                                 const int r32 = min(max(encode32(pr, p0) - lo, 0), W - 1);
                                 const int r64 = min(max(encode64(pr, p0) - lo, 0), W - 1);
-                                nsr[j][k] = (uint32_t)(r32 | (r64 << 8));
+                                out[k] = (uint32_t)(r32 | (r64 << 8));
                             }
-                        } else if ((w & 3u) == 0u) {
-#pragma unroll
-                            for (int k = 0; k < NRSEG; k++) nsr[j][k] = grow[k];
-                        } else {
-                            if (NOISE) {
-                                const uint32_t c0A = ((w >> 8) & 0xFFu) * (uint32_t)A, c1 = (w >> 16) & 0xFFu;
-#pragma unroll
-                                for (int k = 0; k < NRSEG; k++) {
-                                    const uint32_t idx = ((w & 1u) ? c0A : am0A[k]) + ((w & 2u) ? c1 : am1[k]);
-                                    nsr[j][k] = lut_ns[idx];
-                                }
-                            } else {
-                                // idx = greedy part (masked by the not-exploring flags) + precomputed K
-                                const uint32_t nf0 = (w & 1u) ^ 1u, nf1 = ((w >> 1) & 1u) ^ 1u, K2 = (w >> 8) << 1;
-#pragma unroll
-                                for (int k = 0; k < NRSEG; k++) {
-                                    const uint32_t off = __umul24(am0A2[k], nf0) + __umul24(am1x2[k], nf1) + K2;
-                                    nsr[j][k] = *reinterpret_cast<const unsigned short*>(
-                                        reinterpret_cast<const unsigned char*>(lut_ns) + off);
-                                }
-                            }
+                            return;
                         }
                     }
-                    if (t0 + 4 <= n) {          // full group: no per-step bound checks on the chain
+                    const uint32_t sM = readlane_u(Mv, tl), sK = readlane_u(Kv, tl);
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                    for (int k = 0; k < NRSEG; k++) out[k] = lds_load<unsigned short>(halves_sum(R[k] & sM) + sK);
+                };
+                // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step; the state each step was
+                // played in is recorded in lane t of sq.
+                uint32_t sq = 0;
+                auto chain4 = [&](int t0, const uint32_t (&tab)[4][NRSEG]) {
+                    if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
+                        s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
+                        chain_step<true>(sq, s, tab[0][0], t0);
+                        chain_step<false>(sq, s, tab[1][0], t0 + 1);
+                        chain_step<false>(sq, s, tab[2][0], t0 + 2);
+                        chain_step<false>(sq, s, tab[3][0], t0 + 3);
+                        return;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (t0 + j < n) {
                             sq = writelane_u(sq, (uint32_t)s, t0 + j);
-                            s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            if (t0 + j < n) {
-                                sq = writelane_u(sq, (uint32_t)s, t0 + j);
-                                s = (int)read_row<NRSEG>(nsr[j], s & 0xFF);
-                            }
+                            s = (int)read_row<NRSEG>(tab[j], s & 0xFF);
                         }
                     }
+                };
+                // the tables of group g+1 are built (their gathers in flight) while group g's chain runs
+                uint32_t ta[4][NRSEG], tb[4][NRSEG];
+#pragma unroll
+                for (int j = 0; j < 4; j++) build(j, ta[j]);
+                for (int t0 = 0;;) {
+                    if (t0 + 4 < n) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) build(t0 + 4 + j, tb[j]);
+                    }
+                    chain4(t0, ta);
+                    t0 += 4;
+                    if (t0 >= n) break;
+                    if (t0 + 4 < n) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) build(t0 + 4 + j, ta[j]);
+                    }
+                    chain4(t0, tb);
+                    t0 += 4;
+                    if (t0 >= n) break;
                 }
                 seq[seg] = sq;
             }
@@ -572,14 +604,14 @@ k_wave_episodes(const WaveArgs a) {
                 const bool valid = tt < T;
                 const uint32_t a0 = act[seg] & 0xFFu, a1 = (act[seg] >> 8) & 0xFFu;
                 const uint32_t srow = (act[seg] >> 16) & 0xFFu;
-                double price = lut_price[a0 * (uint32_t)A + a1];
-                if (NOISE) {
-                    double pn = __dsub_rn(nav[seg], __dmul_rn(a.env.b, __dadd_rn(lut_aq[a0], lut_aq[A + a1])));
-                    if (!(pn > 0.0)) pn = 0.0;
-                    if (rwv[seg] & 4u) price = pn;
-                }
-                const double r0d = __dmul_rn(price, lut_aq[a0]);
-                const double r1d = __dmul_rn(price, lut_aq[A + a1]);
+                // NoisyPriceState.step (environments.py:25-39) from the staged quantities A_i = (a/b)*scaled_i:
+                // three float64 operations per 64 steps instead of a gather from the L2-resident price table
+                const double aq0 = lut_aq[a0], aq1 = lut_aq[A + a1];
+                const double a_eff = (NOISE && (rwv[seg] & 4u)) ? nav[seg] : a.env.a;
+                double price = __dsub_rn(a_eff, __dmul_rn(a.env.b, __dadd_rn(aq0, aq1)));
+                if (!(price > 0.0)) price = 0.0;
+                const double r0d = __dmul_rn(price, aq0);
+                const double r1d = __dmul_rn(price, aq1);
                 if (seg == NSEG - 1) {
                     const int ll = T - 1 - seg * 64;       // lane of the episode's last step
                     last_price = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(price), ll),
@@ -718,11 +750,25 @@ k_wave_episodes(const WaveArgs a) {
             int32_t* cw0 = a.counter + (int64_t)g * a.stride + p0.table_off;
             int32_t* cw1 = a.counter + (int64_t)g * a.stride + p1.table_off;
             const int nwin = W * A;
-            for (int k = lane; k < nwin; k += 64) {
-                const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
-                const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
-                if (n0) cw0[lo * A + k] += (int32_t)n0;
-                if (n1) cw1[lo * A + k] += (int32_t)n1;
+            // all counter loads of a batch in flight before the first store (one HBM round trip per 512
+            // cells instead of one per 64)
+            for (int k0 = 0; k0 < nwin; k0 += 512) {
+                int32_t c0v[8], c1v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = min(k0 + j * 64 + lane, nwin - 1);
+                    c0v[j] = cw0[lo * A + k]; c1v[j] = cw1[lo * A + k];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = k0 + j * 64 + lane;
+                    if (k < nwin) {
+                        const unsigned n0 = (hist[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                        const unsigned n1 = (hist[hw + (k >> 1)] >> ((k & 1) << 4)) & 0xFFFFu;
+                        if (n0) cw0[lo * A + k] = c0v[j] + (int32_t)n0;
+                        if (n1) cw1[lo * A + k] = c1v[j] + (int32_t)n1;
+                    }
+                }
             }
             if (lane < 2 * A) {
                 const int which = lane >= A, col = lane - which * A;

@@ -10,9 +10,7 @@ struct WaveLut {
                     //               play row (float32 encode) | train row (float64 encode) << 8
     int aq_off;     // double [2][A] (a/b)*scale_i(k): quantity of agent i at action k
     int sct_off;    // double [2][A] scale_i(k)/T: per-step contribution to actions_log
-    int lds_bytes;  // the part above is staged in LDS (the ns LUT is on the serial chain)
-    int price_off;  // double [A*A]  price (= next env state) per action pair; read from the
-                    //               HBM image (L2-resident, 3.5 KB) by the lane-parallel prologue
+    int lds_bytes;  // all of it is staged in LDS
     int bytes;      // total, multiple of 16
 };
 
@@ -22,8 +20,7 @@ __host__ __device__ inline WaveLut wave_lut_layout(int A) {
     l.aq_off = (2 * A * A + 15) & ~15;
     l.sct_off = l.aq_off + 16 * A;
     l.lds_bytes = (l.sct_off + 16 * A + 15) & ~15;
-    l.price_off = l.lds_bytes;
-    l.bytes = (l.price_off + 8 * A * A + 15) & ~15;
+    l.bytes = l.lds_bytes;
     return l;
 }
 

@@ -144,10 +144,16 @@ class MixedGameBatch:
     def init_tables(self):
         torch = _torch()
         with torch.cuda.device(self.device):
+            init_gamma = None
+            if "gamma" in self.sweep:        # only QTable rows move the table offset 12.5/(1-gamma); a neural agent's
+                init_gamma = self.sweep["gamma"].clone()      # placeholder slot keeps its (unused) default
+                for i in self.nn:
+                    init_gamma[i] = float(self.cfg.gamma[i])
             _lib.check(self.L.thrl_qtable_init(ctypes.byref(self.cfg), self._p(self.q), self._p(self.counter),
                                                self._p(self.state), self.seed, self.game_offset,
-                                               self._p(self.sweep.get("gamma")), self._stream()),
+                                               self._p(init_gamma), self._stream()),
                        "thrl_qtable_init")
+            torch.cuda.synchronize(self.device)          # init_gamma is a temporary
         for rb in self.nn.values():
             rb.init()
         self.initialized = True

@@ -35,10 +35,14 @@ class ReinforceBatch:
     def set_sweep(self, gamma=None, entropy=None):
         """Per-game gamma / entropy coefficient (arrays of length G): a config sweep as one batch."""
         torch = _torch()
+        def dev(x):
+            if not isinstance(x, torch.Tensor):
+                x = np.asarray(x, np.float64)
+            return self._dev(x, torch.float64).reshape(self.G).contiguous().clone()
         if gamma is not None:
-            self.gamma_g = self._dev(np.asarray(gamma, np.float64).reshape(self.G), torch.float64)
+            self.gamma_g = dev(gamma)
         if entropy is not None:
-            self.entropy_g = self._dev(np.asarray(entropy, np.float64).reshape(self.G), torch.float64)
+            self.entropy_g = dev(entropy)
         return self
 
     def _stream(self):
