@@ -361,6 +361,26 @@ def test_wave_shapes_vs_oracle(label, config, G, E, dtype):
     np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("eps", [0.0, 0.03])
+def test_wave_greedy_regime_cycles_and_fixed_points_vs_oracle(dtype, eps):
+    """Late-training regime: (almost) always greedy, so games sit in fixed points and short cycles --
+    the replay schedule cuts every group into serial passes and takes the four-identical-transitions
+    path (one row read, four dependent updates in registers).  Bit for bit against the oracle."""
+    ag = dict(CFG_AGENT, epsilon=eps, eps_end=eps)
+    config = {"agents": [dict(ag), dict(ag, alpha=0.3)], "environment": dict(CFG_ENV)}
+    G, E = 300, 7
+    gb = _batch(config, G, dtype=dtype, kernel="wave", seed=77).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    assert out["kernel"] == "wave"
+    q, c, s, e2, mem, oo = _oracle_run(config, G, 1 if dtype == "float64" else 0, q0, s0, E, seed=77)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+    assert np.array_equal(gb.states_numpy(), s)
+    # the regime is what the test is for: most games repeat one cell many times within an episode
+    assert (c.max(axis=1) >= 50).mean() > 0.3
+
+
 def test_zero_episodes_and_odd_sizes():
     """Empty and ragged inputs: 0 episodes is a no-op; G far below / not a multiple of the
     resident wave count."""

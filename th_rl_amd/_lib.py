@@ -4,7 +4,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libthrl_hip.so")
+# THRL_LIB: an alternative build of the SAME ABI (the timing-only ablation variants of profiles/ablate.py)
+LIB_PATH = os.environ.get("THRL_LIB") or os.path.join(HERE, "libthrl_hip.so")
 MAXA = 8
 
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2

@@ -31,7 +31,17 @@
 #include "thrl_kernels.h"
 #include "thrl_wave_lut.h"
 
+// THRL_ABLATE: timing-only diagnostic builds (python -m th_rl_amd.build --ablate MASK, profiles/ablate.py).
+// A set bit removes one phase of the kernel -- results are wrong by construction; the product library is
+// always built with 0.  1 replay passes, 2 play chain, 4 play tables, 8 Philox, 16 per-row argmax,
+// 32 visit counters (log + histogram), 64 log sums, 128 replay schedule.
+#ifndef THRL_ABLATE
+#define THRL_ABLATE 0
+#endif
+
 namespace thrl {
+
+constexpr int kAblate = THRL_ABLATE;
 
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
@@ -200,12 +210,14 @@ template <typename QT> struct BlockOps;
 template <> struct BlockOps<float> {
     unsigned c1;
     __device__ __forceinline__ void permute(unsigned sel) { c1 = bperm(sel, c1); }
+    __device__ __forceinline__ void keep() const { asm volatile("" :: "v"(c1)); }
     __device__ __forceinline__ float value(float nm, float alpha_gamma, float, float) const {
         return __fmaf_rn(alpha_gamma, nm, __builtin_bit_cast(float, c1));
     }
 };
 template <> struct BlockOps<double> {
     unsigned r_lo, r_hi, t4_lo, t4_hi;
+    __device__ __forceinline__ void keep() const { asm volatile("" :: "v"(r_lo), "v"(r_hi), "v"(t4_lo), "v"(t4_hi)); }
     __device__ __forceinline__ void permute(unsigned sel) {
         r_lo = bperm(sel, r_lo); r_hi = bperm(sel, r_hi); t4_lo = bperm(sel, t4_lo); t4_hi = bperm(sel, t4_hi);
     }
@@ -264,25 +276,52 @@ template <> struct HP<double> {
 };
 
 // One 32-transition block of train_net's loop (agents.py:68-76), four transitions per pass.
-// RDN = ceil(A / 8) row reads per lane.
+// RDN = row reads per lane: 3 (A <= 24) or 4.
 //   P        (step layout, lane 4g of the segment): the four next-state rows of group g, 7 bits each,
 //            | cut bits << 28 (bit j-1: a new pass starts before transition j of the group)
+//            | bit 31: the four transitions are IDENTICAL and stay in their row (a converged game sits in a
+//              fixed point: same state, same greedy actions, same reward, step after step).  Serially that
+//              is four dependent (row max, TD value) pairs on one cell; here the row is read once, split
+//              into "the cell" and "max of the rest", and the four pairs run in registers: one store.
 //   ops, wo  operands / LDS store address of transition 4*(lane&7) + ((lane>>3)&3) ("exec layout")
-template <typename QT, int RDN>
+template <typename QT, int RDN, bool FIXED_POINTS>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              const unsigned (&rd_base)[4], unsigned row_shift, unsigned my_step,
-                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma) {
+                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half) {
+    if (kAblate & 1) { ops.keep(); asm volatile("" :: "v"(wo), "v"(P)); return; }
     for (int gi = 0; gi * 4 < nsub; gi++) {
         const uint32_t sP = readlane_u(P, lane_base + gi * 4);
         const int nv = min(4, nsub - gi * 4);
-        const unsigned rowoff = ((sP >> row_shift) & 0x7Fu) * row_bytes;
+        const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
+        unsigned ad[RDN];                                       // this lane's column chunks of its transition's next-state row
+#pragma unroll
+        for (int i = 0; i < RDN; i++) ad[i] = rd_base[i] + rowoff;
+        if (FIXED_POINTS && (sP >> 31) && nv == 4 && !(kAblate & 256)) {
+            // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
+            const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
+            const unsigned cell = upper_half ? c1 : c0;
+            QT rest = -(QT)INFINITY, cur = -(QT)INFINITY;
+#pragma unroll
+            for (int i = 0; i < RDN; i++) {
+                const QT e = lds_load<QT>(ad[i]);
+                rest = max_of(rest, ad[i] == cell ? -(QT)INFINITY : e);
+                cur = max_of(cur, ad[i] == cell ? e : -(QT)INFINITY);
+            }
+            rest = group8_allmax(rest);
+            cur = group8_allmax(cur);
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur = ops.value(max_of(rest, cur), alpha_gamma, alpha, gamma);
+            if (my_step == (unsigned)(gi * 4 + 3)) lds_store<QT>(wo, cur);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
         int lo = 0;
         do {
             const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
-            QT m = lds_load<QT>(rd_base[0] + rowoff);
+            QT m = lds_load<QT>(ad[0]);
 #pragma unroll
-            for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(rd_base[i] + rowoff));
+            for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(ad[i]));
             m = group8_allmax(m);
             const QT val = ops.value(m, alpha_gamma, alpha, gamma);
             if ((unsigned)(my_step - (unsigned)(gi * 4 + lo)) < (unsigned)(hi - lo)) lds_store<QT>(wo, val);
@@ -429,10 +468,10 @@ k_wave_episodes(const WaveArgs a) {
             const double eps0 = sw_eps_on ? epsg0 : a.eps[e][0], eps1 = sw_eps_on ? epsg1 : a.eps[e][1];
 
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
-            //          during play: agents.py only writes it in train_net).  R packs the two
-            //          greedy byte offsets into the u16 payoff LUT: agent 0's (a0*A*2) in the low
+            //          during play: agents.py only writes it in train_net).  AM = a0 | a1 << 8; R packs the
+            //          two greedy byte offsets into the u16 payoff LUT: agent 0's (a0*A*2) in the low
             //          half, agent 1's (a1*2) in the high half.
-            uint32_t am0[NRSEG], am1[NRSEG], R[NRSEG];
+            uint32_t AM[NRSEG], R[NRSEG];
 #pragma unroll
             for (int k = 0; k < NRSEG; k++) {
                 const int row = min(lane + 64 * k, W + 1);
@@ -440,13 +479,15 @@ k_wave_episodes(const WaveArgs a) {
                 const QT* r1 = tab1 + row * A;
                 QT b0 = r0[0], b1 = r1[0];
                 uint32_t i0 = 0, i1 = 0;
+                if (!(kAblate & 16))
 #pragma unroll 4
                 for (int j = 1; j < A; j++) {
                     const QT v0 = r0[j], v1 = r1[j];
                     if (v0 > b0) { b0 = v0; i0 = j; }
                     if (v1 > b1) { b1 = v1; i1 = j; }
                 }
-                am0[k] = i0; am1[k] = i1;
+                if (kAblate & 16) { i0 = (uint32_t)(lane * 5) % (uint32_t)A; i1 = (uint32_t)(lane * 3) % (uint32_t)A; }
+                AM[k] = i0 | (i1 << 8);
                 R[k] = (i0 * (uint32_t)A * 2u) | (i1 << 17);
             }
 
@@ -468,6 +509,9 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t c0 = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(A - 1));
                     const uint32_t c1 = min((uint32_t)(uint8_t)a.inj_choice[k + a.G], (uint32_t)(A - 1));
                     rw = ex0 | ex1 | (c0 << 8) | (c1 << 16);
+                } else if (kAblate & 8) {
+                    const uint32_t h = (uint32_t)(lane * 2654435761u) ^ eg;
+                    rw = (h & 3u) | (((h >> 4) % (uint32_t)A) << 8) | (((h >> 12) % (uint32_t)A) << 16);
                 } else {
                     const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
                     const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
@@ -494,6 +538,8 @@ k_wave_episodes(const WaveArgs a) {
                 //   Mv keeps agent i's half of R iff agent i does NOT explore in this step,
                 //   Kv = LUT base + 2 * (explore0 ? c0*A : 0) + 2 * (explore1 ? c1 : 0)
                 // so address(r) = lo16(R[r] & Mv) + hi16(R[r] & Mv) + Kv: no scalar control per step.
+                // (Deciding the category -- who explores -- on the scalar unit instead needs only 2 vector
+                // instructions per step, but its branches cost more than the 3 it saves: measured 13 % slower.)
                 const uint32_t Mv = ((rw & 1u) ? 0u : 0xFFFFu) | ((rw & 2u) ? 0u : 0xFFFF0000u);
                 const uint32_t Kv = lut_ns_lds + 2u * (((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) +
                                                       ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u));
@@ -510,7 +556,7 @@ k_wave_episodes(const WaveArgs a) {
                             const uint32_t c0 = (w >> 8) & 0xFFu, c1 = (w >> 16) & 0xFFu;
 #pragma unroll
                             for (int k = 0; k < NRSEG; k++) {
-                                const uint32_t a0r = (w & 1u) ? c0 : am0[k], a1r = (w & 2u) ? c1 : am1[k];
+                                const uint32_t a0r = (w & 1u) ? c0 : (AM[k] & 0xFFu), a1r = (w & 2u) ? c1 : (AM[k] >> 8);
                                 const double Q = __dadd_rn(lut_aq[a0r], lut_aq[A + a1r]);
                                 double pr = __dsub_rn(na, __dmul_rn(a.env.b, Q));
                                 if (!(pr > 0.0)) pr = 0.0;
@@ -521,6 +567,11 @@ k_wave_episodes(const WaveArgs a) {
                             return;
                         }
                     }
+                    if (kAblate & 4) {
+#pragma unroll
+                        for (int k = 0; k < NRSEG; k++) out[k] = (R[k] >> 17) + (uint32_t)(t & 3);
+                        return;
+                    }
                     const uint32_t sM = readlane_u(Mv, tl), sK = readlane_u(Kv, tl);
 #pragma unroll
                     for (int k = 0; k < NRSEG; k++) out[k] = lds_load<unsigned short>(halves_sum(R[k] & sM) + sK);
@@ -529,6 +580,11 @@ k_wave_episodes(const WaveArgs a) {
                 // played in is recorded in lane t of sq.
                 uint32_t sq = 0;
                 auto chain4 = [&](int t0, const uint32_t (&tab)[4][NRSEG]) {
+                    if (kAblate & 2) {
+                        asm volatile("" :: "v"(tab[0][0]), "v"(tab[1][0]), "v"(tab[2][0]), "v"(tab[3][0]));
+                        sq = (uint32_t)min(lane, W - 1) * 0x101u;
+                        return;
+                    }
                     if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
                         s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
                         chain_step<true>(sq, s, tab[0][0], t0);
@@ -537,6 +593,7 @@ k_wave_episodes(const WaveArgs a) {
                         chain_step<false>(sq, s, tab[3][0], t0 + 3);
                         return;
                     }
+                    s = __builtin_amdgcn_readfirstlane(s);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (t0 + j < n) {
@@ -582,10 +639,9 @@ k_wave_episodes(const WaveArgs a) {
                 const uint32_t rw = rwv[seg];
                 // gather with ALL lanes active (a bpermute reads only from active lanes, and
                 // the source lane here is a table row, unrelated to this lane's step), then select
-                const uint32_t g0 = gather_row<NRSEG>(am0, my_s);
-                const uint32_t g1 = gather_row<NRSEG>(am1, my_s);
-                uint32_t a0 = (rw & 1u) ? ((rw >> 8) & 0xFFu) : g0;
-                uint32_t a1 = (rw & 2u) ? ((rw >> 16) & 0xFFu) : g1;
+                const uint32_t gam = gather_row<NRSEG>(AM, my_s);
+                uint32_t a0 = (rw & 1u) ? ((rw >> 8) & 0xFFu) : (gam & 0xFFu);
+                uint32_t a1 = (rw & 2u) ? ((rw >> 16) & 0xFFu) : (gam >> 8);
                 uint32_t nxt = (uint32_t)__shfl_down((int)seq[seg], 1, 64);
                 if (seg + 1 < NSEG) { if (lane == 63) nxt = readlane_u(seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
                 const uint32_t ns = (tt + 1 < T) ? ((nxt >> 8) & 0xFFu) : ((uint32_t)s_end >> 8);
@@ -625,7 +681,7 @@ k_wave_episodes(const WaveArgs a) {
                 }
                 // visit counters (agents.py:76): the packed transition word goes to this wave's
                 // log (coalesced, L2-resident); the counts are built per game below
-                if (a.counter)
+                if (a.counter && !(kAblate & 32))
                     a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + e) * NSEG + seg) * 64 + lane] =
                         valid ? act[seg] : 0xFFFFFFFFu;
 
@@ -633,7 +689,8 @@ k_wave_episodes(const WaveArgs a) {
                 //      Transition j may share a pass with an earlier transition i of its group unless it
                 //      reads the row i writes (live next_max, agents.py:71) or rewrites i's cell (:75).
                 uint32_t P;
-                {
+                if (kAblate & 128) P = (act[seg] >> 24) * 0x204081u;
+                else {
                     const uint32_t w = act[seg];
                     const uint32_t b0 = dpp_mov32<0x00>(w), b1 = dpp_mov32<0x55>(w), b2 = dpp_mov32<0xAA>(w),
                                    b3 = dpp_mov32<0xFF>(w);                       // quad broadcasts of positions 0..3
@@ -649,11 +706,13 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t c1 = h1 & 1u;
                     const uint32_t c2 = ((h2 >> 1) & 1u) | ((c1 ^ 1u) & h2 & 1u);
                     const uint32_t c3 = ((h3 >> 2) & 1u) | ((c2 ^ 1u) & (((h3 >> 1) & 1u) | ((c1 ^ 1u) & h3 & 1u)));
+                    const uint32_t same4 = (b0 == b1 && b1 == b2 && b2 == b3 && (b0 >> 24) == ((b0 >> 16) & 0xFFu)) ? 1u : 0u;
                     P = (b0 >> 24) | ((b1 >> 24) << 7) | ((b2 >> 24) << 14) | ((b3 >> 24) << 21) |
-                        ((c1 | (c2 << 1) | (c3 << 2)) << 28);
+                        ((c1 | (c2 << 1) | (c3 << 2)) << 28) | (same4 << 31);
                 }
 
                 // ---- (e) replay (agents.py:68-76): live next_max, writes in transition order
+                const bool any_fixed = __ballot((P >> 31) != 0u) != 0ull;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
@@ -661,19 +720,21 @@ k_wave_episodes(const WaveArgs a) {
                     BlockOps<QT> ops = make_ops(snap[seg], k, r0d, r1d, alpha_h);
                     ops.permute(perm_sel);                                   // step layout -> exec layout
                     const unsigned wo = bperm(perm_sel, k ? woq.y : woq.x);
-                    if (A > 24)
-                        replay_block<QT, 4>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
-                    else if (A > 16)
-                        replay_block<QT, 3>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
-                    else
-                        replay_block<QT, 2>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, ag_h, alpha_h, gamma_h);
+                    // 3 row reads per lane cover 24 columns (fewer columns: clamped duplicates), 4 cover 32.
+                    // The fixed-point path is compiled into a second copy of the loop, entered only when the
+                    // segment has such a group: the common exploring-regime loop stays as tight as without it.
+#define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
+                                                          ag_h, alpha_h, gamma_h, half != 0)
+                    if (A > 24) { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
+                    else        { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
+#undef THRL_REPLAY
                 }
             }
 
             // ---- (f) per-episode log sums of this game into the wave accumulator:
             //      lane L gets the wave total of quantity L&3 = (reward0, reward1, action0, action1)
             {
-                double v = wave_sum4(lr0, lr1, la0, la1, lane);
+                double v = (kAblate & 64) ? lr0 + lr1 + la0 + la1 : wave_sum4(lr0, lr1, la0, la1, lane);
                 if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
                 const long long vq = __double2ll_rn(__dmul_rn(v, log_scale));
                 if ((lane >> 2) == (e & 15)) { if (e < 16) acc += vq; else acc_hi += vq; }
@@ -710,7 +771,7 @@ k_wave_episodes(const WaveArgs a) {
         //      transition log, then apply it to the counter window with plain coalesced
         //      read-add-write -- this game's counters belong to this wave alone, so no
         //      global atomics are needed (2e9 scattered atomics per launch were a 70 ms floor).
-        if (a.counter) {
+        if (a.counter && !(kAblate & 32)) {
             const int cells = (W + 2) * A;                       // per agent
             const int hw = (cells + 1) >> 1;                     // dwords per agent
             // may_alias: the histogram overlays the tables (no type-based reordering)
