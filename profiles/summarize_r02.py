@@ -53,11 +53,16 @@ def main():
         clock_ghz=cycles / t / 1e9,
         insts_per_env_step=dict(valu=m["SQ_INSTS_VALU"] / env_steps, salu=m["SQ_INSTS_SALU"] / env_steps,
                                 lds=m["SQ_INSTS_LDS"] / env_steps, branch=m["SQ_INSTS_BRANCH"] / env_steps),
-        # share of each SIMD's VALU issue slots used: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
-        valu_frac=m["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles),
-        # the same from the time waves spend executing VALU instructions (quad-cycles), summed over a SIMD's waves
+        # VALU issue: a SIMD issues at most one vector instruction per 4-cycle issue slot (what the counters
+        # show here: SALU and VALU both come out at 4 cycles per instruction per SIMD); `valu_frac` = share of
+        # those slots used; `valu_frac_2cyc` prices an instruction at the SIMD-32 execute time of 2 cycles
+        # (MI355X_MICROARCH.md) -- the rate back-to-back independent FMAs from several waves would reach
+        valu_frac=m["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cycles),
+        valu_frac_2cyc=m["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles),
+        # time waves spend executing VALU instructions (quad-cycles x 4), summed over a SIMD's 5 waves, per
+        # SIMD cycle: multi-cycle instructions (float64, 32-bit multiplies, DPP / readlane hazards) included
         valu_active_frac=m["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cycles),
-        salu_frac=m["SQ_INSTS_SALU"] / (N_CU * cycles),       # one scalar unit per CU, one instruction per cycle
+        salu_frac=m["SQ_INSTS_SALU"] * 4.0 / (N_SIMD * cycles),     # scalar issue slots, same pricing
         lds_busy_frac=m["SQ_LDS_IDX_ACTIVE"] / (N_CU * cycles) / 4.0 if "SQ_LDS_IDX_ACTIVE" in m else None,
         lds_bank_conflict_share=m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"],
         # where a wave's time goes (disjoint): issuing / parked on s_waitcnt / stalled at issue

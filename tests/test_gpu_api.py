@@ -268,6 +268,39 @@ def test_protocol_env_step_matches_reference_grid():
     assert s[0] == p and np.array_equal(r, rr) and nu < 1.0
 
 
+def test_encode_operator_fast_path_and_boundary_fallback_vs_numpy():
+    """thrl_op_encode (and the wave kernel's noisy steps) use a division-free encode that falls back to the
+    exact quotient near a rounding boundary.  Checked against numpy's own arithmetic -- QTable.encode is
+    numpy.round(state / max_state * states), agents.py:47-49 -- on random prices, on every half-integer
+    boundary and on its float neighbours, in float64 and in the float32 form the trainer feeds."""
+    import ctypes
+    import torch
+    from th_rl_amd import _lib
+    rs = np.random.RandomState(5)
+    ks = np.arange(0, 100) + 0.5
+    near = []
+    for b in ks / 100.0 * 10.0:                       # prices whose row value sits at k + 0.5
+        x = np.float64(b)
+        for _ in range(4):
+            near += [x, np.nextafter(x, 0.0), np.nextafter(x, 20.0)]
+            x = np.nextafter(x, 20.0)
+        x32 = np.float32(b)
+        near += [np.float64(x32), np.float64(np.nextafter(x32, np.float32(0))), np.float64(np.nextafter(x32, np.float32(20)))]
+    price = np.concatenate([rs.uniform(0, 10, 200000), np.array(near, np.float64), [0.0, 10.0, 9.999999999]])
+    N = len(price)
+    cfg, _ = _lib.cfg_from_config({"agents": [dict(CFG_AGENT)], "environment": dict(CFG_ENV, nplayers=1)}, N, 1)
+    L = _lib.load()
+    d_p = torch.from_numpy(price).cuda()
+    out = torch.zeros(N, dtype=torch.int32, device="cuda")
+    for as_f32 in (0, 1):
+        _lib.check(L.thrl_op_encode(ctypes.byref(cfg), 0, ctypes.c_void_p(d_p.data_ptr()), as_f32,
+                                    ctypes.c_void_p(out.data_ptr()), None), "thrl_op_encode")
+        torch.cuda.synchronize()
+        st = price.astype(np.float32) if as_f32 else price
+        want = np.clip(np.round(st / 10 * 100).astype(np.int64), 0, 100)
+        assert np.array_equal(out.cpu().numpy(), want), as_f32
+
+
 def test_protocol_train_net_matches_reference_known_answers():
     """QTable.memory.append + train_net through thrl_op_td_update == golden G3 cases."""
     from th_rl_amd.agents import QTable

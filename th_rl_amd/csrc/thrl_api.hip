@@ -80,6 +80,8 @@ void fill_agents(const thrl_cfg* c, AgentParams* ag, EnvParams* env) {
             off += p.rows * p.n_actions;
             p.max_state = c->max_state[i];
             p.max_state_f = (float)c->max_state[i];
+            p.inv_max_state = 1.0 / c->max_state[i];
+            p.inv_max_state_f = 1.0f / p.max_state_f;
             p.gamma = c->gamma[i]; p.alpha = c->alpha[i];
             p.one_minus_alpha = 1.0 - c->alpha[i];
             p.gamma_f = (float)c->gamma[i]; p.alpha_f = (float)c->alpha[i];

@@ -62,6 +62,8 @@ struct AgentParams {          // one per agent, by value in the kernel argument 
     int32_t table_off;        // element offset inside a game's slab
     double  max_state;
     float   max_state_f;      // weak-scalar cast used by the float32 encode
+    double  inv_max_state;    // RN(1 / max_state), RN_f32(1 / max_state_f): only for the fast encodes below,
+    float   inv_max_state_f;  // which fall back to the exact division near a rounding boundary
     double  gamma, alpha, one_minus_alpha;
     float   gamma_f, alpha_f, one_minus_alpha_f;
     float   alpha_gamma_f;    // alpha_f * gamma_f, one rounded float product
@@ -85,6 +87,22 @@ __device__ __forceinline__ int encode64(double price, const AgentParams& p) {
 // QTable.encode on the float32-cast state (trainer.py:53 -> agents.py:88)
 __device__ __forceinline__ int encode32(double price, const AgentParams& p) {
     return clamp_row((int)rintf(__fmul_rn(__fdiv_rn((float)price, p.max_state_f), (float)p.n_states)), p);
+}
+// The same two encodes without the division on the common path.  q' = price * RN(1/max_state) is within
+// 1.5 * 2^-52 (relative) of the correctly rounded quotient q, so y' = RN(q' * states) is within 2.5 * 2^-52 |y|
+// of the reference's y = RN(q * states): rint(y') == rint(y) unless a half-integer lies that close to y'.
+// In that case (probability ~1e-13 per call in float64, ~1e-4 in float32) the exact form decides.
+__device__ __forceinline__ int encode64_fast(double price, const AgentParams& p) {
+    const double y = __dmul_rn(__dmul_rn(price, p.inv_max_state), (double)p.n_states);
+    const double r = rint(y);
+    if (fabs(fabs(y - r) - 0.5) <= 0x1p-49 * fabs(y)) return encode64(price, p);      // 8 * 2^-52 |y|: margin 3x
+    return clamp_row((int)r, p);
+}
+__device__ __forceinline__ int encode32_fast(double price, const AgentParams& p) {
+    const float y = __fmul_rn(__fmul_rn((float)price, p.inv_max_state_f), (float)p.n_states);
+    const float r = rintf(y);
+    if (fabsf(fabsf(y - r) - 0.5f) <= 0x1p-20f * fabsf(y)) return encode32(price, p);   // 8 * 2^-23 |y|
+    return clamp_row((int)r, p);
 }
 // QTable.scale (agents.py:51-57)
 __device__ __forceinline__ double scale_action(int action, const AgentParams& p) {

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) k_op_encode(const OpArgs a) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G) return;
     const AgentParams& p = a.ag[a.agent];
-    a.action_out[g] = a.encode32 ? encode32(a.price[g], p) : encode64(a.price[g], p);
+    a.action_out[g] = a.encode32 ? encode32_fast(a.price[g], p) : encode64_fast(a.price[g], p);
 }
 
 // NoisyPriceState.step (environments.py:25-39) on scaled actions [N][G]

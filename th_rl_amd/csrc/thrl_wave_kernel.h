@@ -543,14 +543,15 @@ k_wave_episodes(const WaveArgs a) {
                 const uint32_t Mv = ((rw & 1u) ? 0u : 0xFFFFu) | ((rw & 2u) ? 0u : 0xFFFF0000u);
                 const uint32_t Kv = lut_ns_lds + 2u * (((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) +
                                                       ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u));
+                const unsigned long long noisy_steps = NOISE ? __ballot((rw & 4u) != 0u) : 0ull;   // scalar: no per-step readlane
                 // Phase 1 (off the serial chain, lane = ROW): nsr_t[r] for one step; its LDS gather does
                 // not depend on the current state.
-                auto build = [&](int t, uint32_t (&out)[NRSEG]) {
+                auto build = [&](int t, uint32_t (&out)[NRSEG], bool may_be_noisy) {
                     const int tl = t;            // < 64: only groups that start below n <= 64 are built
-                    if (NOISE) {
-                        const uint32_t w = readlane_u(rw, tl);
-                        if (w & 4u) {
+                    if (NOISE && may_be_noisy) {
+                        if ((noisy_steps >> tl) & 1ull) {
                             // noisy step: the price is not on the LUT; evaluate it for every row
+                            const uint32_t w = readlane_u(rw, tl);
                             const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nav[seg]), tl),
                                                                __builtin_amdgcn_readlane(__double2loint(nav[seg]), tl));
                             const uint32_t c0 = (w >> 8) & 0xFFu, c1 = (w >> 16) & 0xFFu;
@@ -560,8 +561,8 @@ k_wave_episodes(const WaveArgs a) {
                                 const double Q = __dadd_rn(lut_aq[a0r], lut_aq[A + a1r]);
                                 double pr = __dsub_rn(na, __dmul_rn(a.env.b, Q));
                                 if (!(pr > 0.0)) pr = 0.0;
-                                const int r32 = min(max(encode32(pr, p0) - lo, 0), W - 1);
-                                const int r64 = min(max(encode64(pr, p0) - lo, 0), W - 1);
+                                const int r32 = min(max(encode32_fast(pr, p0) - lo, 0), W - 1);
+                                const int r64 = min(max(encode64_fast(pr, p0) - lo, 0), W - 1);
                                 out[k] = (uint32_t)(r32 | (r64 << 8));
                             }
                             return;
@@ -604,20 +605,24 @@ k_wave_episodes(const WaveArgs a) {
                 };
                 // the tables of group g+1 are built (their gathers in flight) while group g's chain runs
                 uint32_t ta[4][NRSEG], tb[4][NRSEG];
+                auto build4 = [&](int t0, uint32_t (&tab)[4][NRSEG]) {
+                    // one scalar test per group of four steps: a group without a noisy step (81 % of them at
+                    // noise_prob 0.05) takes the straight-line path
+                    if (NOISE && ((noisy_steps >> t0) & 0xFull)) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) build(j, ta[j]);
-                for (int t0 = 0;;) {
-                    if (t0 + 4 < n) {
+                        for (int j = 0; j < 4; j++) build(t0 + j, tab[j], true);
+                    } else {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) build(t0 + 4 + j, tb[j]);
+                        for (int j = 0; j < 4; j++) build(t0 + j, tab[j], false);
                     }
+                };
+                build4(0, ta);
+                for (int t0 = 0;;) {
+                    if (t0 + 4 < n) build4(t0 + 4, tb);
                     chain4(t0, ta);
                     t0 += 4;
                     if (t0 >= n) break;
-                    if (t0 + 4 < n) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) build(t0 + 4 + j, ta[j]);
-                    }
+                    if (t0 + 4 < n) build4(t0 + 4, ta);
                     chain4(t0, tb);
                     t0 += 4;
                     if (t0 >= n) break;
