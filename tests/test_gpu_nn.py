@@ -650,3 +650,38 @@ def test_example_config_and_configs2_as_one_sweep_equal_two_separate_runs(tmp_pa
     ref = MixedGameBatch(ex, n_games=2 * Gh, seed=3, sweep=sweep).init_tables(); ref.run(12)
     assert torch.equal(b["q"], ref.q.cpu()) and torch.equal(b["nn"][1]["params"], ref.nn[1].params.cpu())
     assert torch.equal(b["sweep"]["gamma"], ref.sweep["gamma"].cpu())
+
+
+@pytest.mark.parametrize("pair", ["rr", "qr", "qa", "qc"])
+def test_full_size_properties_65536_games_neural(pair):
+    """BASELINE config #4 at its full size (65,536 games) for 2 x Reinforce and for QTable vs Reinforce /
+    ActorCritic / CAC, through the fused episode kernel and the batched update kernels: properties that
+    need no oracle.  Every agent appends exactly E*T transitions and trains every min_memory of them; all
+    parameters / Adam moments / tables stay finite and move; visit counters sum to E*T; rewards stay in
+    the payoff band of the action grid (price in [2, 6], quantity in [2, 4] -> reward in [4, 24])."""
+    import torch
+    from th_rl_amd.mixed import MixedGameBatch
+    G, E, T = 65536, 20, 100
+    nn_ag = {"r": dict(R_AGENT), "a": dict(R_AGENT, name="ActorCritic", gamma=0.98),
+             "c": {"name": "CAC", "gamma": 0.98, "states": 1, "action_range": [0.2, 0.4]}}
+    first = dict(R_AGENT) if pair[0] == "r" else dict(Q_AGENT)
+    config = {"agents": [first, nn_ag[pair[1]]], "environment": dict(ENV)}
+    mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=5).init_tables()
+    w0 = {i: rb.params.clone() for i, rb in mb.nn.items()}
+    out = mb.run(E, per_game_logs=False)
+    assert out["kernel"] == "mixed-fused"
+    for i, rb in mb.nn.items():
+        assert rb.step == E * T // 1000                       # one update per min_memory = 1,000 transitions
+        for name in ("params", "adam_m", "adam_v"):
+            assert bool(torch.isfinite(getattr(rb, name)).all()), (i, name)
+        moved = (rb.params != w0[i]).any(dim=1)
+        assert bool(moved.all()), "some game's network never trained"
+        assert mb.count[i] == 0                               # buffer emptied by the last update
+    if pair[0] == "q":
+        c = mb.counter[:, :101 * 21].sum(dim=1)
+        assert bool((c == E * T).all())                       # QTable.counter: one visit per transition (agents.py:76)
+        assert bool(torch.isfinite(mb.q).all())
+    r = out["reward_log"]
+    assert r.shape == (E, 2) and np.isfinite(r).all() and (r > 4.0).all() and (r < 24.0).all()
+    a = out["action_log"]
+    assert ((a >= 0.2) & (a <= 0.4)).all()
