@@ -348,7 +348,11 @@ def main():
         if tj and tj.get("kernel") == gb.last_kernel and default_cfg and "model" in tj:
             m = tj["model"]
             traffic = float(G) * (m["bytes_per_game_per_launch"] + m["bytes_per_game_per_episode"] * e_launch)
-            issue = tj.get("issue")
+            issue = dict(tj.get("issue") or {})
+            sc = issue.pop("occupancy_scaling", None)           # keep the line compact: only the fitted share
+            if sc:
+                issue["latency_share_at_20_waves"] = sc.get("latency_share_at_20_waves")
+            issue = issue or None
         out = {
             "metric": "env-steps/sec, 2-agent PD x 1M parallel games",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,

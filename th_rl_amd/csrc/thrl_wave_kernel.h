@@ -163,21 +163,33 @@ __device__ __forceinline__ uint32_t halves_sum(uint32_t x) {
     return y;
 }
 
-// One step of the play chain for a one-register row table: lane t of `sq` <- s (the state step t is
-// played in), then s <- nsr[s & 63].  Hand-placed wait states (hipcc does not look inside asm):
-// a v_readlane whose lane select was written by a VALU (the previous step's v_readlane) needs 4 wait
-// states -- previous v_writelane + s_nop 1 + s_mov = 4 (FIRST: nothing is known about the instruction
-// before, so s_nop 2 + s_mov) -- and v_writelane needs 1 after the s_mov of M0 (the v_readlane).
-template <bool FIRST>
-__device__ __forceinline__ void chain_step(uint32_t& sq, int& s, uint32_t nsr, int t) {
-    int s_new;
-    if (FIRST)
-        asm volatile("s_nop 2\n\ts_mov_b32 m0, %4\n\tv_readlane_b32 %1, %3, %2\n\tv_writelane_b32 %0, %2, m0"
-                     : "+v"(sq), "=&s"(s_new) : "s"(s), "v"(nsr), "s"(t));
-    else
-        asm volatile("s_nop 1\n\ts_mov_b32 m0, %4\n\tv_readlane_b32 %1, %3, %2\n\tv_writelane_b32 %0, %2, m0"
-                     : "+v"(sq), "=&s"(s_new) : "s"(s), "v"(nsr), "s"(t));
-    s = s_new;
+// Four steps of the play chain for one-register row tables: s <- nsr_j[s & 63] for j = 0..3, and the
+// four states the steps were played in recorded TWO PER LANE (lane t0: s_t0 | s_t0+1 << 16, lane t0+2:
+// s_t0+2 | s_t0+3 << 16; the caller unpacks lane-parallel) -- 6 vector instructions per group instead of 8.
+// Hand-placed wait states (hipcc does not look inside asm): a v_readlane whose lane select was written by
+// a VALU (the previous v_readlane) needs 4 wait states; the s_mov / s_add of M0, the s_pack and the
+// v_writelane fill them where they can, s_nop pads the rest.  v_writelane needs 1 after M0 changes.
+__device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, int t0) {
+    int s1, s2, s3, s4, pk;
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_readlane_b32 %1, %7, %6\n\t"
+        "s_mov_b32 m0, %11\n\t"
+        "s_nop 2\n\t"
+        "v_readlane_b32 %2, %8, %1\n\t"
+        "s_pack_ll_b32_b16 %5, %6, %1\n\t"
+        "v_writelane_b32 %0, %5, m0\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %3, %9, %2\n\t"
+        "s_add_u32 m0, m0, 2\n\t"
+        "s_nop 2\n\t"
+        "v_readlane_b32 %4, %10, %3\n\t"
+        "s_pack_ll_b32_b16 %5, %2, %3\n\t"
+        "v_writelane_b32 %0, %5, m0"
+        : "+v"(sq), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(pk)
+        : "s"(s), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "s"(t0)
+        : "scc");
+    s = s4;
 }
 
 // value of a lane-indexed-by-row register pair at (uniform) row s
@@ -579,26 +591,23 @@ k_wave_episodes(const WaveArgs a) {
                 };
                 // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step; the state each step was
                 // played in is recorded in lane t of sq.
-                uint32_t sq = 0;
+                uint32_t sq = 0, sq_tail = 0;          // sq: two states per lane (full groups); sq_tail: one per lane
                 auto chain4 = [&](int t0, const uint32_t (&tab)[4][NRSEG]) {
                     if (kAblate & 2) {
                         asm volatile("" :: "v"(tab[0][0]), "v"(tab[1][0]), "v"(tab[2][0]), "v"(tab[3][0]));
-                        sq = (uint32_t)min(lane, W - 1) * 0x101u;
+                        sq_tail = (uint32_t)min(lane, W - 1) * 0x101u;
                         return;
                     }
                     if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
                         s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
-                        chain_step<true>(sq, s, tab[0][0], t0);
-                        chain_step<false>(sq, s, tab[1][0], t0 + 1);
-                        chain_step<false>(sq, s, tab[2][0], t0 + 2);
-                        chain_step<false>(sq, s, tab[3][0], t0 + 3);
+                        chain_group(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0], t0);
                         return;
                     }
                     s = __builtin_amdgcn_readfirstlane(s);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         if (t0 + j < n) {
-                            sq = writelane_u(sq, (uint32_t)s, t0 + j);
+                            sq_tail = writelane_u(sq_tail, (uint32_t)s, t0 + j);
                             s = (int)read_row<NRSEG>(tab[j], s & 0xFF);
                         }
                     }
@@ -627,7 +636,12 @@ k_wave_episodes(const WaveArgs a) {
                     t0 += 4;
                     if (t0 >= n) break;
                 }
-                seq[seg] = sq;
+                {   // unpack: lanes below the last full group of the hand-scheduled path hold two states per even lane
+                    const int packed_end = (NRSEG == 1 && !(kAblate & 2)) ? (n & ~3) : 0;
+                    const uint32_t prev = dpp_mov32<0x111>(sq);                 // row_shr:1 -- lane t-1 (t odd: same row)
+                    const uint32_t un = (lane & 1) ? (prev >> 16) : (sq & 0xFFFFu);
+                    seq[seg] = lane < packed_end ? un : sq_tail;
+                }
             }
             const int s_end = s;
 
