@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--noise-prob", type=float, default=None,
                     help="diagnostic: NoisyPriceState noise_prob (config value 0; class default 0.05)")
+    ap.add_argument("--max-steps", type=int, default=None,
+                    help="diagnostic: environment.max_steps (config value 100); with the QTable default min_memory = 100 "
+                         "a smaller value makes the replay buffer span episodes (training cycles)")
+    ap.add_argument("--capacity", type=int, default=None, help="diagnostic: QTable.capacity (default 500)")
     ap.add_argument("--epsilon", type=float, default=None,
                     help="diagnostic: start from this epsilon instead of the config's 0.5 "
                          "(e.g. 0.001 = the late-training, greedy-dominated regime)")
@@ -285,6 +289,12 @@ def main():
     chunk = max(1, min(32, chunk))
     if args.noise_prob is not None:
         CFG["environment"]["noise_prob"] = float(args.noise_prob)
+    T_run = T_STEPS
+    if args.max_steps is not None:
+        CFG["environment"]["max_steps"] = T_run = int(args.max_steps)
+    if args.capacity is not None:
+        for ag in CFG["agents"]:
+            ag["capacity"] = int(args.capacity)
     gb = GameBatch(CFG, n_games=G, device=dev, dtype=args.dtype, kernel=args.kernel, seed=0,
                    game_offset=rank * G, counters=not args.no_counters).init_tables()
 
@@ -329,7 +339,7 @@ def main():
         per_rank = [float(x[0]) for x in allr]
 
     if rank == 0:
-        total_env_steps = float(n_gpus) * G * T_STEPS * args.steps
+        total_env_steps = float(n_gpus) * G * T_run * args.steps
         value = total_env_steps / elapsed
         # dominant kernel: k_wave_episodes; HIP events on the launch stream bracket each launch
         full = [(a.elapsed_time(b) * 1e-3, e) for a, b, e in events if e == chunk] or \
@@ -337,14 +347,14 @@ def main():
         times = sorted(t for t, _ in full)
         avg_launch_s = sum(times) / len(times)
         e_launch = full[0][1]
-        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * G * T_STEPS * e_launch
+        algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * G * T_run * e_launch
         achieved = algo_bytes_launch / avg_launch_s / 1e9
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
         # corrections: profiles/summarize.py): bytes = G * (per_game + per_game_episode * E)
         traffic, issue = None, None
         tj = _load_json("traffic.json")
         default_cfg = (args.noise_prob in (None, 0.0) and args.epsilon is None and not args.no_counters
-                       and args.dtype == "float32")
+                       and args.dtype == "float32" and args.max_steps is None and args.capacity is None)
         if tj and tj.get("kernel") == gb.last_kernel and default_cfg and "model" in tj:
             m = tj["model"]
             traffic = float(G) * (m["bytes_per_game_per_launch"] + m["bytes_per_game_per_episode"] * e_launch)
@@ -360,8 +370,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": "2-agent QTable (21 actions x 101 states, example_config.json) x %d "
-                                   "parallel NoisyPriceState games per GPU, T=100, fused step+TD kernel"
-                                   % G,
+                                   "parallel NoisyPriceState games per GPU, T=%d, fused step+TD kernel"
+                                   % (G, T_run),
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
                        "counters": not args.no_counters, "epsilon_start": 0.5 if args.epsilon is None else args.epsilon,
                        "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus},
@@ -383,7 +393,7 @@ def main():
         if world > 1:
             # N = 1-equivalent figures so a SCALE record can be checked against BENCH directly
             out["per_rank"] = {"games_per_gpu": G, "seconds": per_rank,
-                               "value": [G * T_STEPS * args.steps / s for s in per_rank]}
+                               "value": [G * T_run * args.steps / s for s in per_rank]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

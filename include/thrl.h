@@ -142,6 +142,12 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* cfg);
 size_t thrl_workspace_bytes(const thrl_cfg* cfg);
 /* which kernel THRL_KERNEL_AUTO would pick for this config (thrl_kernel) */
 int    thrl_select_kernel(const thrl_cfg* cfg, int injected);
+/* Training cycle of the wave kernel: the replay buffers (buffers.py:12-19) reach min_memory every k-th
+ * episode (agents.py:60), k = ceil(min_memory / max_steps); a call runs on the wave kernel when its
+ * n_episodes is a multiple of k and the buffers are empty on entry (thrl_run.mem_count == 0), otherwise on
+ * the generic kernel, which keeps the buffers in replay_mem.  Returns k >= 1, or 0 when the config is the
+ * generic kernel's anyway. */
+int    thrl_training_cycle(const thrl_cfg* cfg);
 
 /*
  * Replaces QTable.__init__ table/counter init (agents.py:29,45) and

@@ -381,6 +381,59 @@ def test_wave_greedy_regime_cycles_and_fixed_points_vs_oracle(dtype, eps):
     assert (c.max(axis=1) >= 50).mean() > 0.3
 
 
+def _cycle_config(T, mm, cap, noise=0.0):
+    ag = dict(CFG_AGENT, min_memory=mm, capacity=cap)
+    return {"agents": [dict(ag), dict(ag, alpha=0.3, gamma=0.9)], "environment": dict(CFG_ENV, max_steps=T, noise_prob=noise)}
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("label,config,k,E", [
+    ("T50_trains_every_2nd", _cycle_config(50, 100, 500), 2, 6),
+    ("T10_trains_every_10th", _cycle_config(10, 100, 500), 10, 20),
+    ("T30_mm70_every_3rd", _cycle_config(30, 70, 500), 3, 6),
+    ("T100_deque_overflow_cap64", _cycle_config(100, 20, 64), 1, 4),           # only the last 64 transitions train
+    ("T60_cycle_and_overflow", _cycle_config(60, 100, 100), 2, 6),             # 120 appended, 100 kept
+    ("never_trains", _cycle_config(40, 100, 50), 1, 5),                        # capacity < min_memory
+    ("T100_mm150_two_episodes_noise", _cycle_config(100, 150, 500, noise=0.1), 2, 4),   # 200 transitions: 4 segments
+])
+def test_wave_training_cycles_vs_oracle(label, config, k, E, dtype):
+    """Replay buffers that span episodes (max_steps < min_memory: train_net trains every k-th episode on k*T
+    transitions), deque overflow (only the last `capacity` transitions train) and buffers that never reach
+    min_memory, on the LDS-resident wave kernel: bit for bit against the oracle, over two calls; a call
+    that is not a whole number of cycles runs on the generic kernel and continues exactly."""
+    import ctypes
+    G, qd = 41, (1 if dtype == "float64" else 0)
+    gb = _batch(config, G, dtype=dtype, kernel="auto", seed=14).init_tables()
+    assert gb.L.thrl_training_cycle(ctypes.byref(gb.cfg)) == k
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    o1 = gb.run(E)
+    assert o1["kernel"] == "wave", label
+    q, c, s, eps, mem, oo = _oracle_run(config, G, qd, q0, s0, E, seed=14)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c), label
+    assert np.array_equal(gb.states_numpy(), s)
+    assert [float(x) for x in gb.eps[:2]] == [float(x) for x in eps[:2]]
+    np.testing.assert_allclose(o1["reward_log"], oo["reward_log"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(o1["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13)
+    if label == "never_trains":
+        assert np.array_equal(q, q0) and not c.any()
+    # k + 1 more episodes: not a whole number of cycles -> generic kernel, buffers kept; then back in step
+    extra = k + 1 if k > 1 else 2
+    o2 = gb.run(extra)
+    assert o2["kernel"] == ("generic" if k > 1 else "wave")
+    cfg, _ = O.cfg_from_config(config, n_games=G, q_dtype=qd)
+    O.episodes(cfg, q, c, s, eps, mem, extra, seed=14, first_episode=E)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c), label
+    if k > 1:
+        o3 = gb.run(k - 1)                                  # completes the cycle on the generic kernel
+        assert o3["kernel"] == "generic"
+        O.episodes(cfg, q, c, s, eps, mem, k - 1, seed=14, first_episode=E + extra)
+        assert np.array_equal(gb.tables_numpy(), q)
+        o4 = gb.run(k)                                      # buffers are empty again: wave kernel
+        assert o4["kernel"] == "wave"
+        O.episodes(cfg, q, c, s, eps, mem, k, seed=14, first_episode=E + extra + k - 1)
+        assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), c)
+
+
 def test_zero_episodes_and_odd_sizes():
     """Empty and ragged inputs: 0 episodes is a no-op; G far below / not a multiple of the
     resident wave count."""

@@ -68,12 +68,23 @@ def test_host_logic_layout_and_kernel_selection(lib):
     assert lib.thrl_select_kernel(ctypes.byref(cfgn), 0) == _lib.KERNEL_WAVE       # noise + per-agent alpha
     cfg64, _ = _lib.cfg_from_config(CFG, 1 << 20, 1)
     assert lib.thrl_select_kernel(ctypes.byref(cfg64), 0) == _lib.KERNEL_WAVE       # float64 tables: same kernel, QT = double
-    for mod, why in [(dict(T=30), "min_memory"),
-                     (dict(nag=3), "2 agents"), (dict(cap=64), "capacity")]:
+    # buffers that span episodes (max_steps 30 < min_memory 100: trains every 4th episode on 120 transitions)
+    # and deque overflow for BOTH agents are training cycles of the wave kernel
+    for mod in (dict(T=30), dict(capboth=64), dict(T=10)):
+        c = json.loads(json.dumps(CFG))
+        if "T" in mod: c["environment"]["max_steps"] = mod["T"]
+        if "capboth" in mod:
+            for a in c["agents"]: a["capacity"] = mod["capboth"]; a["min_memory"] = 20
+        cfgw, _ = _lib.cfg_from_config(c, 64, 0)
+        assert lib.thrl_select_kernel(ctypes.byref(cfgw), 0) == _lib.KERNEL_WAVE, mod
+    for mod, why in [(dict(mm=300), "256 transitions"), (dict(T=3), "32 episodes"),
+                     (dict(nag=3), "2 agents"), (dict(cap=64), "cycles")]:
         c = json.loads(json.dumps(CFG))
         if "noise" in mod: c["environment"]["noise_prob"] = mod["noise"]
         if "T" in mod: c["environment"]["max_steps"] = mod["T"]
         if "cap" in mod: c["agents"][0]["capacity"] = mod["cap"]
+        if "mm" in mod:
+            for a in c["agents"]: a["min_memory"] = mod["mm"]
         if "nag" in mod: c["agents"].append(dict(CFG_AGENT)); c["environment"]["nplayers"] = 3
         cfg2, _ = _lib.cfg_from_config(c, 64, mod.get("q", 0))
         assert lib.thrl_select_kernel(ctypes.byref(cfg2), 0) == _lib.KERNEL_GENERIC, mod

@@ -77,7 +77,7 @@ class Mixed(ctypes.Structure):
 # every symbol include/thrl.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "thrl_version", "thrl_last_error", "thrl_table_stride", "thrl_table_offset",
-    "thrl_replay_mem_bytes", "thrl_workspace_bytes", "thrl_select_kernel", "thrl_qtable_init",
+    "thrl_replay_mem_bytes", "thrl_workspace_bytes", "thrl_select_kernel", "thrl_training_cycle", "thrl_qtable_init",
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
     "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
@@ -128,6 +128,8 @@ def load():
     L.thrl_table_offset.argtypes = [cfgp, ctypes.c_int]
     L.thrl_select_kernel.restype = ctypes.c_int
     L.thrl_select_kernel.argtypes = [cfgp, ctypes.c_int]
+    L.thrl_training_cycle.restype = ctypes.c_int
+    L.thrl_training_cycle.argtypes = [cfgp]
     L.thrl_qtable_init.restype = ctypes.c_int
     L.thrl_qtable_init.argtypes = [cfgp, vp, vp, vp, u64, u64, vp, vp]
     L.thrl_qtable_episodes.restype = ctypes.c_int

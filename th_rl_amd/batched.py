@@ -181,8 +181,13 @@ class GameBatch:
                         raise ThrlError("injected noise draws must have shape [E,T,G]")
                     b.inj_noise_u, b.inj_noise_a = (self._ptr(dev(nu, torch.float64)),
                                                     self._ptr(dev(na, torch.float64)))
-            will_generic = (self.kernel == _lib.KERNEL_GENERIC or per_game_logs
-                            or self.planned_kernel(injected) == "generic"
+            # the wave kernel runs whole training cycles from empty buffers; anything else is the generic
+            # kernel's, which keeps the buffers in replay_mem between calls
+            cycle = int(self.L.thrl_training_cycle(ctypes.byref(self.cfg)))
+            will_generic = (self.kernel == _lib.KERNEL_GENERIC or per_game_logs or cycle == 0
+                            or E % max(cycle, 1) != 0
+                            or (bool(self.sweep) and not all(self.cfg.min_memory[i] <= T <= self.cfg.capacity[i]
+                                                                 for i in range(N)))
                             or any(self.mem_count[i] for i in range(N)))
             if will_generic and self.kernel != _lib.KERNEL_WAVE:
                 self._ensure_replay_mem()

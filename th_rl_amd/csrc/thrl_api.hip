@@ -117,6 +117,7 @@ struct WavePlan {
     bool ok;
     char why[200];
     int row_lo, win_rows;
+    int epk, replay_from;           // training cycle: episodes per train_net that trains, first kept transition
     int lut_bytes, game_lds_bytes, waves_per_block, blocks_per_cu;
 };
 
@@ -170,12 +171,26 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
         c->max_state[0] != c->max_state[1]) NO("agents must share the state/action grid sizes");
     const int A = c->n_actions[0], T = c->max_steps;
     if (A > 32) NO("actions > 32");
-    if (T > 256) NO("max_steps > 256");
+    // Training cycle (buffers.py:12-19, agents.py:60,77): after every episode len(memory) = min(appends,
+    // capacity); train_net trains -- and empties the buffer -- once that reaches min_memory, i.e. every
+    // epk = ceil(min_memory / T)-th episode, on the last min(epk*T, capacity) transitions.  Both agents
+    // must share the cycle and the kept suffix (or both never train: capacity < min_memory).
+    int epk = 0, keep = 0;
     for (int i = 0; i < 2; i++) {
-        if (T < c->min_memory[i]) NO("max_steps < min_memory (buffer spans episodes)");
-        if (T > c->capacity[i]) NO("max_steps > capacity (deque overflow)");
+        const int cap = c->capacity[i], mm = c->min_memory[i] > 0 ? c->min_memory[i] : 1;
+        const int k_i = cap >= mm && cap > 0 ? (mm + T - 1) / T : 0;           // 0: never trains
+        const int keep_i = k_i ? (k_i * T < cap ? k_i * T : cap) : 0;
+        if (i == 0) { epk = k_i; keep = keep_i; }
+        else if (k_i != epk || keep_i != keep) NO("the agents' replay buffers fill / train on different cycles");
         if (run && run->mem_count[i] != 0) NO("non-empty replay memory on entry");
     }
+    const bool never = epk == 0;
+    if (never) epk = 1;
+    if ((long)epk * T > 256) NO("more than 256 transitions per training cycle");
+    if (epk > kWaveMaxEpisodes) NO("more than 32 episodes per training cycle");
+    if (run && run->n_episodes % epk != 0) NO("episodes of this call are not a multiple of the training cycle");
+    p.epk = epk;
+    p.replay_from = never ? epk * T : epk * T - keep;
     // Row window = every row a step can land in: both encodes (play: float32, train: float64)
     // of the price on the whole action grid; with noise the intercept ranges over [0.7a, a).
     int lo = 1 << 30, hi = -1;
@@ -215,7 +230,7 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     // crowded SIMD's waves some speed (noise window: 3 x 5 waves measured 12 % faster than 3 x 4).
     // register limit: the float32 variants are compiled for 5 waves/SIMD (4 with noise or T > 128),
     // the float64 ones (twice the LDS per game) for 3
-    const int reg_waves = 4 * (c->q_dtype == 1 ? 3 : ((c->noise_prob > 0.0 || c->max_steps > 128) ? 4 : 5));
+    const int reg_waves = 4 * (c->q_dtype == 1 ? 3 : ((c->noise_prob > 0.0 || c->max_steps * p.epk > 128) ? 4 : 5));
     if (cap_waves > reg_waves) cap_waves = reg_waves;
     for (int w = 1; w <= 16; w++) {
         const int lds = p.lut_bytes + w * p.game_lds_bytes;
@@ -253,7 +268,7 @@ WaveWs wave_workspace(const thrl_cfg* c, const WavePlan& p) {
     const int max_grid = dev_info().cus * p.blocks_per_cu;
     if (w.grid > max_grid) w.grid = max_grid;
     w.total_waves = w.grid * p.waves_per_block;
-    const size_t nseg = (size_t)(c->max_steps + 63) / 64;
+    const size_t nseg = (size_t)(c->max_steps * p.epk + 63) / 64;
     w.partial_off = kLutRegion;
     w.tlog_off = w.partial_off + align_up((size_t)w.total_waves * 4 * kWaveMaxEpisodes * sizeof(long long), 256);
     w.bytes = w.tlog_off + align_up((size_t)w.total_waves * kWaveMaxEpisodes * nseg * 64 * sizeof(uint32_t), 256);
@@ -295,6 +310,12 @@ int thrl_select_kernel(const thrl_cfg* c, int injected) {
     const WavePlan p = plan_wave(c, nullptr, injected != 0);
     if (!p.ok) { snprintf(g_err, sizeof(g_err), "generic kernel: %s", p.why); return THRL_KERNEL_GENERIC; }
     return THRL_KERNEL_WAVE;
+}
+
+int thrl_training_cycle(const thrl_cfg* c) {
+    if (validate(c) != THRL_OK) return 0;
+    const WavePlan p = plan_wave(c, nullptr, false);
+    return p.ok ? p.epk : 0;
 }
 
 int thrl_qtable_init(const thrl_cfg* c, void* q, int32_t* counter, double* state, uint64_t seed,
@@ -389,6 +410,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     memset(&a, 0, sizeof(a));
     a.G = c->n_games; a.T = c->max_steps; a.A = c->n_actions[0]; a.rows = c->n_states[0] + 1;
     a.row_lo = p.row_lo; a.win_rows = p.win_rows;
+    a.epk = p.epk; a.replay_from = p.replay_from;
     a.waves_per_block = p.waves_per_block;
     a.lut_bytes = p.lut_bytes; a.game_lds_bytes = p.game_lds_bytes;
     a.stride = (int64_t)thrl_table_stride(c);
@@ -421,6 +443,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
         return fail(THRL_ERR_NULL, "sweep_eps_end / sweep_eps_step need the per-game epsilon state sweep_eps");
     if (b->sweep_noise_prob && !(c->noise_prob > 0.0))
         return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it sizes the row window)");
+    const int chunk_max = kWaveMaxEpisodes / p.epk * p.epk;        // whole training cycles per launch
 
     const int block = p.waves_per_block * 64;
     const int grid = ws.grid;                             // persistent grid; games are handed out by a work counter
@@ -431,7 +454,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     if (e) return hip_fail(e, "k_wave_lut launch");
     int done = 0;
     while (done < run->n_episodes) {
-        const int n = run->n_episodes - done < kWaveMaxEpisodes ? run->n_episodes - done : kWaveMaxEpisodes;
+        const int n = run->n_episodes - done < chunk_max ? run->n_episodes - done : chunk_max;
         a.n_episodes = n;
         a.first_episode = run->first_episode + (uint64_t)done;
         if (b->inj_u) {                                  // parity mode: this chunk's slice of the draws
@@ -479,6 +502,9 @@ int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run
     if (k != THRL_KERNEL_GENERIC) {
         WavePlan p = plan_wave(c, run, injected);
         if (p.ok && per_game_logs) { p.ok = false; snprintf(p.why, sizeof(p.why), "per-game logs requested"); }
+        if (p.ok && (p.epk > 1 || p.replay_from > 0) && (b->sweep_gamma || b->sweep_alpha || b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob)) {
+            p.ok = false; snprintf(p.why, sizeof(p.why), "per-game sweeps with a multi-episode training cycle or a truncated deque");
+        }
         if (p.ok) return run_wave(c, b, run, p, (hipStream_t)stream);
         if (k == THRL_KERNEL_WAVE) return fail(THRL_ERR_UNSUPPORTED, "wave kernel cannot run this config: %s", p.why);
     }

@@ -44,7 +44,11 @@ struct GenericArgs {
 constexpr int kWaveMaxEpisodes = 32;   // 32 episodes x 4 log values = the 64 lanes of two accumulators
 
 struct WaveArgs {
-    int32_t G, T, A, rows;          // homogeneous 2-agent game
+    int32_t G, T, A, rows;          // homogeneous 2-agent game; T = max_steps
+    int32_t epk;                    // episodes per training cycle: the buffer reaches min_memory every epk-th
+                                    // episode (buffers.py / agents.py:60); epk * T <= 256 transitions
+    int32_t replay_from;            // first transition of a cycle that is still in the deque when it trains
+                                    // (epk*T - min(epk*T, capacity); == epk*T: the agents never train)
     int32_t row_lo, win_rows;       // LDS window = rows [row_lo, row_lo+win_rows) + 1 spill row
     int32_t n_episodes;
     int32_t waves_per_block;
@@ -85,6 +89,11 @@ int launch_wave_f32_sweep(const WaveArgs& a, int grid, int block, size_t lds_byt
 int launch_wave_f64_plain(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f64_noise(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f64_sweep(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+// CYCLE = true variants: training cycles of several episodes and / or transitions dropped from the deque
+int launch_wave_f32_plain_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f32_noise_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_plain_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_noise_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_reduce(const long long* partial, const double* log_scale, int total_waves, int n_episodes, int G,
                        double* reward_log, double* action_log, hipStream_t s);
 

@@ -1,10 +1,10 @@
-// thrl_wave_f32n.hip -- instantiates k_wave_episodes<float, *, *, NOISE=true, SWEEP=false> (thrl_wave_kernel.h)
+// thrl_wave_f32n.hip -- instantiates k_wave_episodes<float, *, *, NOISE=true, SWEEP=false, CYCLE=false> (thrl_wave_kernel.h)
 #include "thrl_wave_kernel.h"
 
 namespace thrl {
 
 int launch_wave_f32_noise(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    return launch_wave_n<float, true, false>(a, grid, block, lds, s);
+    return launch_wave_n<float, true, false, false>(a, grid, block, lds, s);
 }
 
 }  // namespace thrl

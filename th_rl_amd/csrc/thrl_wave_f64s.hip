@@ -1,10 +1,10 @@
-// thrl_wave_f64s.hip -- instantiates k_wave_episodes<double, *, *, NOISE=true, SWEEP=true> (thrl_wave_kernel.h)
+// thrl_wave_f64s.hip -- instantiates k_wave_episodes<double, *, *, NOISE=true, SWEEP=true, CYCLE=false> (thrl_wave_kernel.h)
 #include "thrl_wave_kernel.h"
 
 namespace thrl {
 
 int launch_wave_f64_sweep(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    return launch_wave_n<double, true, true>(a, grid, block, lds, s);
+    return launch_wave_n<double, true, true, false>(a, grid, block, lds, s);
 }
 
 }  // namespace thrl

@@ -299,16 +299,20 @@ template <> struct HP<double> {
 template <typename QT, int RDN, bool FIXED_POINTS>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              const unsigned (&rd_base)[4], unsigned row_shift, unsigned my_step,
-                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half) {
+                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
+                                             int block_step0, int replay_from) {
     if (kAblate & 1) { ops.keep(); asm volatile("" :: "v"(wo), "v"(P)); return; }
     for (int gi = 0; gi * 4 < nsub; gi++) {
+        // transitions that had already dropped out of the deque when the buffer trained are skipped
+        const int first = replay_from - (block_step0 + gi * 4);      // <= 0: the whole group trains
+        if (first >= 4) continue;
         const uint32_t sP = readlane_u(P, lane_base + gi * 4);
         const int nv = min(4, nsub - gi * 4);
         const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
         unsigned ad[RDN];                                       // this lane's column chunks of its transition's next-state row
 #pragma unroll
         for (int i = 0; i < RDN; i++) ad[i] = rd_base[i] + rowoff;
-        if (FIXED_POINTS && (sP >> 31) && nv == 4 && !(kAblate & 256)) {
+        if (FIXED_POINTS && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256)) {
             // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
             const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
             const unsigned cell = upper_half ? c1 : c0;
@@ -328,7 +332,8 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
             continue;
         }
         const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
-        int lo = 0;
+        int lo = max(first, 0);
+        if (lo >= nv) continue;
         do {
             const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
             QT m = lds_load<QT>(ad[0]);
@@ -350,14 +355,20 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
 // its larger row window leaves room for fewer waves, so the register budget is relaxed.
 // SWEEP: per-game hyper-parameter arrays (thrl_buffers.sweep_*); compiled only together with NOISE
 // so the headline variant carries none of that state.
-template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP>
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE>
 __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int A = a.A, W = a.win_rows, T = a.T, lo = a.row_lo;
+    // A training cycle = epk episodes played against frozen tables (the replay buffer reaches min_memory
+    // every epk-th episode), then ONE train_net over the transitions still in the deque.  T = transitions
+    // per cycle; for the reference's example configs epk = 1 and a cycle is an episode.
+    // CYCLE = false: the variant for epk == 1 with nothing dropped from the deque (min_memory <= T <= capacity),
+    // compiled without any of the cycle bookkeeping.
+    const int A = a.A, W = a.win_rows, Tenv = a.T, epk = CYCLE ? a.epk : 1, T = a.T * epk, lo = a.row_lo;
+    const int replay_from = CYCLE ? a.replay_from : 0;
     const WaveLut L = wave_lut_layout(A);
 
     {   // stage the payoff LUT once per block
@@ -387,7 +398,7 @@ k_wave_episodes(const WaveArgs a) {
 
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
-    const double inv_T_den = (double)T;
+    const double inv_T_den = (double)Tenv;
 
     // lane ((e&15)*4+k): sum over this wave's games of episode-e log value k (e < 16 / e >= 16), as
     // fixed-point integers: the games a wave gets are not deterministic, integer sums do not care
@@ -475,9 +486,8 @@ k_wave_episodes(const WaveArgs a) {
 
         int s = sp_l | (st_l << 8);          // current state: play row | train row << 8
         double last_price = price0;
-        for (int e = 0; e < a.n_episodes; e++) {
+        for (int e = 0; e < a.n_episodes; e += epk) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
-            const double eps0 = sw_eps_on ? epsg0 : a.eps[e][0], eps1 = sw_eps_on ? epsg1 : a.eps[e][1];
 
             // ---- (a) greedy action of every local row, lane = row (the table is frozen
             //          during play: agents.py only writes it in train_net).  AM = a0 | a1 << 8; R packs the
@@ -512,10 +522,18 @@ k_wave_episodes(const WaveArgs a) {
                 const int n = min(64, T - seg * 64);
                 uint32_t rw;
                 nav[seg] = 0.0;
+                // this lane's step: episode ep of the cycle, step st of that episode; its epsilon
+                const int tcl = min(seg * 64 + lane, T - 1);
+                const int ep = epk == 1 ? 0 : tcl / Tenv;
+                const uint32_t st_in_ep = (uint32_t)(tcl - ep * Tenv);
+                double eps0, eps1;
+                if (sw_eps_on) { eps0 = epsg0; eps1 = epsg1; }                       // (sweeps: epk == 1)
+                else if (epk == 1) { eps0 = a.eps[e][0]; eps1 = a.eps[e][1]; }
+                else { eps0 = a.eps[e + ep][0]; eps1 = a.eps[e + ep][1]; }            // per-lane read of the launch's table
                 if (a.inj_u) {
                     // parity mode: the reference's recorded draws, [E][T][2][G] (agents.py:81-82)
-                    const int tt = min(seg * 64 + lane, T - 1);
-                    const size_t k = (((size_t)e * T + tt) * 2) * (size_t)a.G + (size_t)g;
+                    const int tt = tcl;
+                    const size_t k = (((size_t)e * Tenv + tt) * 2) * (size_t)a.G + (size_t)g;
                     const uint32_t ex0 = a.inj_u[k] < eps0 ? 1u : 0u;
                     const uint32_t ex1 = a.inj_u[k + a.G] < eps1 ? 2u : 0u;
                     const uint32_t c0 = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(A - 1));
@@ -525,7 +543,7 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t h = (uint32_t)(lane * 2654435761u) ^ eg;
                     rw = (h & 3u) | (((h >> 4) % (uint32_t)A) << 8) | (((h >> 12) % (uint32_t)A) << 16);
                 } else {
-                    const u32x4 x = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), 0u);
+                    const u32x4 x = draw(a.seed, gid, eg + (uint32_t)ep, st_in_ep, 0u);
                     const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
                     const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
                     rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) | (__umulhi(x.w, (uint32_t)A) << 16);
@@ -533,11 +551,10 @@ k_wave_episodes(const WaveArgs a) {
                 if (NOISE) {               // environments.py:28-29, bit 2 of rw = noisy step
                     double nu, na;
                     if (a.inj_u) {
-                        const int tt = min(seg * 64 + lane, T - 1);
-                        const size_t k = ((size_t)e * T + tt) * (size_t)a.G + (size_t)g;
+                        const size_t k = ((size_t)e * Tenv + tcl) * (size_t)a.G + (size_t)g;
                         nu = a.inj_noise_u[k]; na = a.inj_noise_a[k];
                     } else {
-                        const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)(seg * 64 + lane), kStreamNoise);
+                        const u32x4 xn = draw(a.seed, gid, eg + (uint32_t)ep, st_in_ep, kStreamNoise);
                         nu = u01_32(xn.x);
                         na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
                     }
@@ -672,6 +689,12 @@ k_wave_episodes(const WaveArgs a) {
             __builtin_amdgcn_wave_barrier();
 
             double lr0 = 0.0, lr1 = 0.0, la0 = 0.0, la1 = 0.0;
+            auto log_into = [&](int epi, double q0, double q1, double q2, double q3) {
+                double v = (kAblate & 64) ? q0 + q1 + q2 + q3 : wave_sum4(q0, q1, q2, q3, lane);
+                if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
+                const long long vq = __double2ll_rn(__dmul_rn(v, log_scale));
+                if ((lane >> 2) == (epi & 15)) { if (epi < 16) acc += vq; else acc_hi += vq; }
+            };
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 // ---- (d2) rewards, LDS write addresses, logs, visit counters of this segment
@@ -694,9 +717,21 @@ k_wave_episodes(const WaveArgs a) {
                 }
                 const v2u woq = pack_halves(tab0_off + (srow * A + a0) * (unsigned)sizeof(QT),
                                             tab1_off + (srow * A + a1) * (unsigned)sizeof(QT));
-                if (valid) {
-                    lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
-                    la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
+                if (epk == 1) {
+                    if (valid) {
+                        lr0 += r0d; lr1 += r1d;          // divided by T once per episode below
+                        la0 += lut_sct[a0]; la1 += lut_sct[A + a1];
+                    }
+                } else {
+                    // several episodes per cycle: this segment's part of each episode's sums goes to that
+                    // episode's accumulator slot (fixed point: exact whatever the split)
+                    const int ep_l = min(tt, T - 1) / Tenv;
+                    const int j0 = (seg * 64) / Tenv, j1 = (min(T, seg * 64 + 64) - 1) / Tenv;
+                    const double s0 = lut_sct[a0], s1 = lut_sct[A + a1];
+                    for (int j = j0; j <= j1; j++) {
+                        const bool m = valid && ep_l == j;
+                        log_into(e + j, m ? r0d : 0.0, m ? r1d : 0.0, m ? s0 : 0.0, m ? s1 : 0.0);
+                    }
                 }
                 // visit counters (agents.py:76): the packed transition word goes to this wave's
                 // log (coalesced, L2-resident); the counts are built per game below
@@ -743,7 +778,7 @@ k_wave_episodes(const WaveArgs a) {
                     // The fixed-point path is compiled into a second copy of the loop, entered only when the
                     // segment has such a group: the common exploring-regime loop stays as tight as without it.
 #define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
-                                                          ag_h, alpha_h, gamma_h, half != 0)
+                                                          ag_h, alpha_h, gamma_h, half != 0, seg * 64 + k * 32, replay_from)
                     if (A > 24) { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
                     else        { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
 #undef THRL_REPLAY
@@ -752,12 +787,7 @@ k_wave_episodes(const WaveArgs a) {
 
             // ---- (f) per-episode log sums of this game into the wave accumulator:
             //      lane L gets the wave total of quantity L&3 = (reward0, reward1, action0, action1)
-            {
-                double v = (kAblate & 64) ? lr0 + lr1 + la0 + la1 : wave_sum4(lr0, lr1, la0, la1, lane);
-                if ((lane & 3) < 2) v = __ddiv_rn(v, inv_T_den);
-                const long long vq = __double2ll_rn(__dmul_rn(v, log_scale));
-                if ((lane >> 2) == (e & 15)) { if (e < 16) acc += vq; else acc_hi += vq; }
-            }
+            if (epk == 1) log_into(e, lr0, lr1, la0, la1);
             // epsilon decays after every train_net call (agents.py:78)
             if (SWEEP) {
                 epsg0 = __dadd_rn(eend0, __dmul_rn(__dsub_rn(epsg0, eend0), estep0));
@@ -801,26 +831,28 @@ k_wave_episodes(const WaveArgs a) {
             __builtin_amdgcn_wave_barrier();
             // log read-back: 4 episodes' loads in flight at a time (sc1 = L2-served: the wave
             // reads what it stored itself)
-            for (int e0 = 0; e0 < a.n_episodes; e0 += 4) {
+            const int n_cycles = a.n_episodes / epk;
+            for (int c0 = 0; c0 < n_cycles; c0 += 4) {
                 unsigned w[4][NSEG];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int seg = 0; seg < NSEG; seg++)
                         w[j][seg] = __hip_atomic_load(
-                            &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + min(e0 + j, a.n_episodes - 1)) * NSEG + seg) * 64 + lane],
+                            &a.tlog[(((size_t)wave_gid * kWaveMaxEpisodes + min(c0 + j, n_cycles - 1) * epk) * NSEG + seg) * 64 + lane],
                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int seg = 0; seg < NSEG; seg++) {
                         const unsigned ww = w[j][seg];
-                        if (e0 + j < a.n_episodes && ww != 0xFFFFFFFFu) {
+                        // only transitions still in the deque when it trained were counted (agents.py:76)
+                        if (c0 + j < n_cycles && ww != 0xFFFFFFFFu && seg * 64 + lane >= replay_from) {
                             const unsigned srow = (ww >> 16) & 0xFFu;
-                            const unsigned c0 = srow * (unsigned)A + (ww & 0xFFu);
-                            const unsigned c1 = srow * (unsigned)A + ((ww >> 8) & 0xFFu);
-                            __hip_atomic_fetch_add(&hist[c0 >> 1], 1u << ((c0 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            __hip_atomic_fetch_add(&hist[hw + (c1 >> 1)], 1u << ((c1 & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            const unsigned c0_ = srow * (unsigned)A + (ww & 0xFFu);
+                            const unsigned c1_ = srow * (unsigned)A + ((ww >> 8) & 0xFFu);
+                            __hip_atomic_fetch_add(&hist[c0_ >> 1], 1u << ((c0_ & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_fetch_add(&hist[hw + (c1_ >> 1)], 1u << ((c1_ & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         }
                     }
             }
@@ -869,9 +901,9 @@ k_wave_episodes(const WaveArgs a) {
     a.partial[(size_t)wave_gid * 128 + 64 + lane] = acc_hi;
 }
 
-template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP>
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE>
 static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    auto kern = k_wave_episodes<QT, NSEG, NRSEG, NOISE, SWEEP>;
+    auto kern = k_wave_episodes<QT, NSEG, NRSEG, NOISE, SWEEP, CYCLE>;
     if (lds > 64 * 1024) {                       // beyond the default dynamic-LDS limit (float64 tables: one block per CU)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -881,23 +913,23 @@ static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hip
     return (int)hipGetLastError();
 }
 
-template <typename QT, bool NOISE, bool SWEEP>
+template <typename QT, bool NOISE, bool SWEEP, bool CYCLE>
 static int launch_wave_n(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    const int nseg = (a.T + 63) / 64;
+    const int nseg = (a.T * a.epk + 63) / 64;
     const int nrseg = (a.win_rows + 2 + 63) / 64;
     if (nrseg == 1) {
         switch (nseg) {
-            case 1: return launch_wave_t<QT, 1, 1, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<QT, 2, 1, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<QT, 3, 1, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<QT, 4, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<QT, 1, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
         }
     } else if (nrseg == 2) {
         switch (nseg) {
-            case 1: return launch_wave_t<QT, 1, 2, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<QT, 2, 2, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<QT, 3, 2, NOISE, SWEEP>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<QT, 4, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<QT, 1, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
         }
     }
     return -1;
