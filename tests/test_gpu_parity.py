@@ -582,11 +582,13 @@ def test_full_size_properties_65536_games():
     assert 9.0 < ra["reward_log"].mean() < 12.6
 
 
-def test_full_size_properties_1M_games():
-    """BASELINE config[2] size (2^20 games): visit-count and finiteness invariants."""
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_full_size_properties_1M_games(dtype):
+    """BASELINE config[2] size (2^20 games), float32 and the reference's float64: visit-count and finiteness
+    invariants; the two dtypes play the same first episode (same draws, tables equal to float32 rounding)."""
     import torch
     G, E = 1 << 20, 3
-    a = _batch(CFG, G, kernel="wave", seed=8).init_tables()
+    a = _batch(CFG, G, dtype=dtype, kernel="wave", seed=8).init_tables()
     r = a.run(E)
     assert r["kernel"] == "wave"
     half = a.stride // 2
@@ -594,3 +596,22 @@ def test_full_size_properties_1M_games():
     assert bool((a.counter[:, half:].sum(dim=1) == E * 100).all())
     assert bool(torch.isfinite(a.q).all())
     assert 9.0 < r["reward_log"].mean() < 12.6
+    st = a.state
+    assert float(st.min()) >= 2.0 - 1e-9 and float(st.max()) <= 6.0 + 1e-9
+
+
+def test_full_size_properties_training_cycles_65536_games():
+    """Buffers that span episodes at BASELINE config[1] size: max_steps 50 with min_memory 100 trains every
+    2nd episode on 100 transitions; every agent's visit count is exactly the number of trained transitions;
+    wave == generic on device."""
+    import torch
+    config = _cycle_config(50, 100, 500)
+    G, E = 65536, 8
+    a = _batch(config, G, kernel="wave", seed=4).init_tables()
+    b = _batch(config, G, kernel="generic", seed=4).init_tables()
+    ra = a.run(E); rb = b.run(E)
+    assert ra["kernel"] == "wave" and rb["kernel"] == "generic"
+    half = a.stride // 2
+    assert bool((a.counter[:, :half].sum(dim=1) == E * 50).all())
+    assert torch.equal(a.q, b.q) and torch.equal(a.counter, b.counter) and torch.equal(a.state, b.state)
+    np.testing.assert_allclose(ra["reward_log"], rb["reward_log"], rtol=1e-12)
