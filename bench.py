@@ -257,6 +257,10 @@ def main():
     ap.add_argument("--epsilon", type=float, default=None,
                     help="diagnostic: start from this epsilon instead of the config's 0.5 "
                          "(e.g. 0.001 = the late-training, greedy-dominated regime)")
+    ap.add_argument("--pretrain", type=int, default=0,
+                    help="diagnostic: train this many episodes (untimed, natural epsilon decay) before the warm-up, "
+                         "so the timed region runs on TRAINED tables at the epsilon a real run has by then "
+                         "(the reference's config trains 20,000 episodes; epsilon is 0.004 after 10,000)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -319,6 +323,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.pretrain > 0:
+        done = 0
+        while done < args.pretrain:
+            e = min(32, args.pretrain - done)
+            gb.run(e, sync=False)
+            done += e
+        torch.cuda.synchronize(dev)
+    eps_at_start = float(gb.eps[0])
     run_steps(args.warmup)
     barrier()
     events = []
@@ -354,7 +366,8 @@ def main():
         traffic, issue = None, None
         tj = _load_json("traffic.json")
         default_cfg = (args.noise_prob in (None, 0.0) and args.epsilon is None and not args.no_counters
-                       and args.dtype == "float32" and args.max_steps is None and args.capacity is None)
+                       and args.dtype == "float32" and args.max_steps is None and args.capacity is None
+                       and args.pretrain == 0)
         if tj and tj.get("kernel") == gb.last_kernel and default_cfg and "model" in tj:
             m = tj["model"]
             traffic = float(G) * (m["bytes_per_game_per_launch"] + m["bytes_per_game_per_episode"] * e_launch)
@@ -373,7 +386,7 @@ def main():
                                    "parallel NoisyPriceState games per GPU, T=%d, fused step+TD kernel"
                                    % (G, T_run),
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
-                       "counters": not args.no_counters, "epsilon_start": 0.5 if args.epsilon is None else args.epsilon,
+                       "counters": not args.no_counters, "epsilon_start": eps_at_start, "pretrain_episodes": args.pretrain,
                        "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus},
             "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
