@@ -9,9 +9,13 @@ Workload (BASELINE.json metric / configs[2]): 2 QTable age
 (example_config.json QTable block) x 2^20 parallel NoisyPriceState games PER GPU,
 float32 tables, int32 visit counters, Philox draws, synthetic random-init tables.
 One "step" = one episode (T=100 env-steps, both agents acting and learning) of every
-game.  A kernel launch covers --chunk episodes (tables stay in LDS inside a launch);
-by default chunk = steps // 4 (at most 32), so the timed region always holds >= 4 launches
-and the per-launch HIP-event average is over >= 4 samples.
+game.  A kernel launch covers --chunk episodes (tables stay in LDS inside a launch; 32 at most);
+by default the K steps of a timed region are ONE launch when K <= 32 (what a training loop does:
+trainer.train_one launches 25-32 episodes at a time), otherwise equal launches of <= 32.  The
+timed region -- exactly K steps between barrier + synchronize on both sides, max over ranks -- is
+repeated until >= 4 launches have been timed (K = 20: four regions) and the MEDIAN region is
+reported; every region's time is in the line (`region_ms`), the per-launch HIP-event average of
+the roofline block is over all of them.
 Multi-GPU: games are seed-sharded (game_offset = rank * games), no data-path
 collective; a gloo group provides only the barrier and the max-over-ranks clock.
 
@@ -235,7 +239,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--games", type=int, default=1 << 20, help="games per GPU")
     ap.add_argument("--chunk", type=int, default=0,
-                    help="episodes per kernel launch (<=32); default steps // 4 so that >= 4 launches are timed")
+                    help="episodes per kernel launch (<=32); default: the whole region when steps <= 32, else equal "
+                         "launches of <= 32 episodes")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="how many times the timed K-step region is run (median reported); default: enough for >= 4 "
+                         "timed launches")
     ap.add_argument("--nn-loop", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--nn-agents", default="rr", choices=["rr", "qr", "qq", "qa", "qc"])
     ap.add_argument("--kernel", default="wave", choices=["wave", "generic", "auto"])
@@ -289,8 +297,13 @@ def main():
     torch.cuda.set_device(dev)
 
     G = args.games
-    chunk = args.chunk if args.chunk > 0 else max(1, args.steps // 4)
-    chunk = max(1, min(32, chunk))
+    if args.chunk > 0:
+        chunk = max(1, min(32, args.chunk))
+    else:
+        n_launch = (args.steps + 31) // 32
+        chunk = max(1, (args.steps + n_launch - 1) // n_launch)
+    launches_per_region = (args.steps + chunk - 1) // chunk
+    regions = args.regions if args.regions > 0 else max(1, (4 + launches_per_region - 1) // launches_per_region)
     if args.noise_prob is not None:
         CFG["environment"]["noise_prob"] = float(args.noise_prob)
     T_run = T_STEPS
@@ -334,21 +347,28 @@ def main():
     run_steps(args.warmup)
     barrier()
     events = []
-    t0 = time.perf_counter()
-    run_steps(args.steps, events)
-    torch.cuda.synchronize(dev)
-    own = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [own]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-        allr = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(allr, torch.tensor([own], dtype=torch.float64))
-        per_rank = [float(x[0]) for x in allr]
+    region_s, region_own = [], []
+    for _ in range(regions):
+        t0 = time.perf_counter()
+        run_steps(args.steps, events)
+        torch.cuda.synchronize(dev)
+        own = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        per = [own]
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt[0])
+            allr = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(allr, torch.tensor([own], dtype=torch.float64))
+            per = [float(x[0]) for x in allr]
+        region_s.append(el)
+        region_own.append(per)
+        barrier()
+    mid = sorted(range(regions), key=lambda i: region_s[i])[regions // 2]      # the median region (of an even count: the slower middle one)
+    elapsed, per_rank = region_s[mid], region_own[mid]
 
     if rank == 0:
         total_env_steps = float(n_gpus) * G * T_run * args.steps
@@ -380,6 +400,7 @@ def main():
             "metric": "env-steps/sec, 2-agent PD x 1M parallel games",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "regions": regions, "region_ms": [t * 1e3 for t in region_s],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": "2-agent QTable (21 actions x 101 states, example_config.json) x %d "
