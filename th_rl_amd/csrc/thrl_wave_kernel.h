@@ -288,7 +288,8 @@ template <> struct HP<double> {
 };
 
 // One 32-transition block of train_net's loop (agents.py:68-76), four transitions per pass.
-// RDN = row reads per lane: 3 (A <= 24) or 4.
+// RDN = row reads per lane: 2 (A = 2), 3 (A <= 24) or 4; a lane reads RDN CONSECUTIVE columns of its
+// transition's next-state row (one address: the loads differ by an immediate offset).
 //   P        (step layout, lane 4g of the segment): the four next-state rows of group g, 7 bits each,
 //            | cut bits << 28 (bit j-1: a new pass starts before transition j of the group)
 //            | bit 31: the four transitions are IDENTICAL and stay in their row (a converged game sits in a
@@ -298,7 +299,7 @@ template <> struct HP<double> {
 //   ops, wo  operands / LDS store address of transition 4*(lane&7) + ((lane>>3)&3) ("exec layout")
 template <typename QT, int RDN, bool FIXED_POINTS>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
-                                             const unsigned (&rd_base)[4], unsigned row_shift, unsigned my_step,
+                                             unsigned rd_base, unsigned row_shift, unsigned my_step,
                                              unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
                                              int block_step0, int replay_from) {
     if (kAblate & 1) { ops.keep(); asm volatile("" :: "v"(wo), "v"(P)); return; }
@@ -309,9 +310,9 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
         const uint32_t sP = readlane_u(P, lane_base + gi * 4);
         const int nv = min(4, nsub - gi * 4);
         const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
-        unsigned ad[RDN];                                       // this lane's column chunks of its transition's next-state row
+        unsigned ad[RDN];                                       // this lane's columns of its transition's next-state row
 #pragma unroll
-        for (int i = 0; i < RDN; i++) ad[i] = rd_base[i] + rowoff;
+        for (int i = 0; i < RDN; i++) ad[i] = rd_base + rowoff + (unsigned)(i * sizeof(QT));
         if (FIXED_POINTS && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256)) {
             // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
             const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
@@ -392,9 +393,10 @@ k_wave_episodes(const WaveArgs a) {
     const unsigned my_step = (unsigned)(4 * jj + kk);
     const unsigned row_shift = (unsigned)(7 * kk);
     const unsigned row_bytes = (unsigned)A * (unsigned)sizeof(QT);
-    unsigned rd_base[4];                                                     // column chunks jj, jj+8, ... (clamped)
-#pragma unroll
-    for (int i = 0; i < 4; i++) rd_base[i] = (half ? tab1_off : tab0_off) + (unsigned)sizeof(QT) * (unsigned)min(jj + 8 * i, A - 1);
+    // replay row reads: lane jj of an 8-lane group reads columns rdn*jj .. rdn*jj + rdn-1 (the last lanes
+    // re-read the row's last rdn columns), rdn = 2 / 3 / 4 for A = 2 / <= 24 / <= 32
+    const int rdn = A < 3 ? 2 : (A <= 24 ? 3 : 4);
+    const unsigned rd_base = (half ? tab1_off : tab0_off) + (unsigned)sizeof(QT) * (unsigned)min(rdn * jj, A - rdn);
 
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
@@ -779,8 +781,9 @@ k_wave_episodes(const WaveArgs a) {
                     // segment has such a group: the common exploring-regime loop stays as tight as without it.
 #define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
                                                           ag_h, alpha_h, gamma_h, half != 0, seg * 64 + k * 32, replay_from)
-                    if (A > 24) { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
-                    else        { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
+                    if (A > 24)      { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
+                    else if (A >= 3) { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
+                    else             { if (any_fixed) THRL_REPLAY(2, true); else THRL_REPLAY(2, false); }
 #undef THRL_REPLAY
                 }
             }
