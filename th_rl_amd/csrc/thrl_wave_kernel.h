@@ -28,6 +28,7 @@
 //     several passes) is computed lane-parallel before the loop, so results are exactly those of the
 //     serial loop.
 #pragma once
+#include <type_traits>
 #include "thrl_kernels.h"
 #include "thrl_wave_lut.h"
 
@@ -169,7 +170,8 @@ __device__ __forceinline__ uint32_t halves_sum(uint32_t x) {
 // Hand-placed wait states (hipcc does not look inside asm): a v_readlane whose lane select was written by
 // a VALU (the previous v_readlane) needs 4 wait states; the s_mov / s_add of M0, the s_pack and the
 // v_writelane fill them where they can, s_nop pads the rest.  v_writelane needs 1 after M0 changes.
-__device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, int t0) {
+template <int T0>
+__device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3) {
     int s1, s2, s3, s4, pk;
     asm volatile(
         "s_nop 3\n\t"
@@ -187,7 +189,7 @@ __device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, u
         "s_pack_ll_b32_b16 %5, %2, %3\n\t"
         "v_writelane_b32 %0, %5, m0"
         : "+v"(sq), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(pk)
-        : "s"(s), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "s"(t0)
+        : "s"(s), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "n"(T0)
         : "scc");
     s = s4;
 }
@@ -521,7 +523,10 @@ k_wave_episodes(const WaveArgs a) {
             double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
-                const int n = min(64, T - seg * 64);
+                int n = min(64, T - seg * 64);
+                // opaque to the optimiser: the unrolled play loop's "is this group inside the segment" tests stay
+                // scalar compares here instead of being hoisted out of the episode loop as spilled booleans
+                asm volatile("" : "+s"(n));
                 uint32_t rw;
                 nav[seg] = 0.0;
                 // this lane's step: episode ep of the cycle, step st of that episode; its epsilon
@@ -611,7 +616,8 @@ k_wave_episodes(const WaveArgs a) {
                 // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step; the state each step was
                 // played in is recorded in lane t of sq.
                 uint32_t sq = 0, sq_tail = 0;          // sq: two states per lane (full groups); sq_tail: one per lane
-                auto chain4 = [&](int t0, const uint32_t (&tab)[4][NRSEG]) {
+                auto chain4 = [&](auto t0c, const uint32_t (&tab)[4][NRSEG]) {
+                    constexpr int t0 = decltype(t0c)::value;
                     if (kAblate & 2) {
                         asm volatile("" :: "v"(tab[0][0]), "v"(tab[1][0]), "v"(tab[2][0]), "v"(tab[3][0]));
                         sq_tail = (uint32_t)min(lane, W - 1) * 0x101u;
@@ -619,7 +625,7 @@ k_wave_episodes(const WaveArgs a) {
                     }
                     if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
                         s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
-                        chain_group(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0], t0);
+                        chain_group<t0>(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0]);
                         return;
                     }
                     s = __builtin_amdgcn_readfirstlane(s);
@@ -644,17 +650,21 @@ k_wave_episodes(const WaveArgs a) {
                         for (int j = 0; j < 4; j++) build(t0 + j, tab[j], false);
                     }
                 };
+                // Fully unrolled over the segment's 16 groups of four steps (step numbers become immediates: no
+                // index arithmetic or loop control per step; a group past the segment's end costs one scalar test).
                 build4(0, ta);
-                for (int t0 = 0;;) {
-                    if (t0 + 4 < n) build4(t0 + 4, tb);
-                    chain4(t0, ta);
-                    t0 += 4;
-                    if (t0 >= n) break;
-                    if (t0 + 4 < n) build4(t0 + 4, ta);
-                    chain4(t0, tb);
-                    t0 += 4;
-                    if (t0 >= n) break;
+#define THRL_PLAY2(G)                                                                        \
+                if ((G) * 4 < n) {                                                           \
+                    if ((G) * 4 + 4 < n) build4((G) * 4 + 4, tb);                            \
+                    chain4(std::integral_constant<int, (G) * 4>(), ta);                      \
+                    if ((G) * 4 + 4 < n) {                                                   \
+                        if ((G) * 4 + 8 < n) build4((G) * 4 + 8, ta);                        \
+                        chain4(std::integral_constant<int, (G) * 4 + 4>(), tb);              \
+                    }                                                                        \
                 }
+                THRL_PLAY2(0) THRL_PLAY2(2) THRL_PLAY2(4) THRL_PLAY2(6)
+                THRL_PLAY2(8) THRL_PLAY2(10) THRL_PLAY2(12) THRL_PLAY2(14)
+#undef THRL_PLAY2
                 {   // unpack: lanes below the last full group of the hand-scheduled path hold two states per even lane
                     const int packed_end = (NRSEG == 1 && !(kAblate & 2)) ? (n & ~3) : 0;
                     const uint32_t prev = dpp_mov32<0x111>(sq);                 // row_shr:1 -- lane t-1 (t odd: same row)
