@@ -300,54 +300,72 @@ template <> struct HP<double> {
 //              into "the cell" and "max of the rest", and the four pairs run in registers: one store.
 //   ops, wo  operands / LDS store address of transition 4*(lane&7) + ((lane>>3)&3) ("exec layout")
 template <typename QT, int RDN, bool FIXED_POINTS>
+__device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
+                                             unsigned rd_base, unsigned row_shift, unsigned my_step,
+                                             unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
+                                             int block_step0, int replay_from) {
+    // transitions that had already dropped out of the deque when the buffer trained are skipped
+    const int first = replay_from - (block_step0 + gi * 4);      // <= 0: the whole group trains
+    if (first >= 4) return;
+    const uint32_t sP = readlane_u(P, lane_base + gi * 4);
+    const int nv = min(4, nsub - gi * 4);
+    const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
+    unsigned ad[RDN];                                       // this lane's columns of its transition's next-state row
+#pragma unroll
+    for (int i = 0; i < RDN; i++) ad[i] = rd_base + rowoff + (unsigned)(i * sizeof(QT));
+    if (FIXED_POINTS && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256)) {
+        // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
+        const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
+        const unsigned cell = upper_half ? c1 : c0;
+        QT rest = -(QT)INFINITY, cur = -(QT)INFINITY;
+#pragma unroll
+        for (int i = 0; i < RDN; i++) {
+            const QT e = lds_load<QT>(ad[i]);
+            rest = max_of(rest, ad[i] == cell ? -(QT)INFINITY : e);
+            cur = max_of(cur, ad[i] == cell ? e : -(QT)INFINITY);
+        }
+        rest = group8_allmax(rest);
+        cur = group8_allmax(cur);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur = ops.value(max_of(rest, cur), alpha_gamma, alpha, gamma);
+        if (my_step == (unsigned)(gi * 4 + 3)) lds_store<QT>(wo, cur);
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+    const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
+    int lo = max(first, 0);
+    if (lo >= nv) return;
+    do {
+        const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
+        QT m = lds_load<QT>(ad[0]);
+#pragma unroll
+        for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(ad[i]));
+        m = group8_allmax(m);
+        const QT val = ops.value(m, alpha_gamma, alpha, gamma);
+        if ((unsigned)(my_step - (unsigned)(gi * 4 + lo)) < (unsigned)(hi - lo)) lds_store<QT>(wo, val);
+        __builtin_amdgcn_wave_barrier();
+        lo = hi;
+    } while (lo < nv);
+}
+// UNROLL: the block's 8 groups as straight-line code (group numbers become immediates, no loop control):
+// the headline variants; the others keep the loop (code size; hipcc 7.2 also fails on the unrolled noise variants).
+template <typename QT, int RDN, bool FIXED_POINTS, bool UNROLL>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              unsigned rd_base, unsigned row_shift, unsigned my_step,
                                              unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
                                              int block_step0, int replay_from) {
     if (kAblate & 1) { ops.keep(); asm volatile("" :: "v"(wo), "v"(P)); return; }
-    for (int gi = 0; gi * 4 < nsub; gi++) {
-        // transitions that had already dropped out of the deque when the buffer trained are skipped
-        const int first = replay_from - (block_step0 + gi * 4);      // <= 0: the whole group trains
-        if (first >= 4) continue;
-        const uint32_t sP = readlane_u(P, lane_base + gi * 4);
-        const int nv = min(4, nsub - gi * 4);
-        const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
-        unsigned ad[RDN];                                       // this lane's columns of its transition's next-state row
+    if (UNROLL) {
 #pragma unroll
-        for (int i = 0; i < RDN; i++) ad[i] = rd_base + rowoff + (unsigned)(i * sizeof(QT));
-        if (FIXED_POINTS && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256)) {
-            // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
-            const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
-            const unsigned cell = upper_half ? c1 : c0;
-            QT rest = -(QT)INFINITY, cur = -(QT)INFINITY;
-#pragma unroll
-            for (int i = 0; i < RDN; i++) {
-                const QT e = lds_load<QT>(ad[i]);
-                rest = max_of(rest, ad[i] == cell ? -(QT)INFINITY : e);
-                cur = max_of(cur, ad[i] == cell ? e : -(QT)INFINITY);
-            }
-            rest = group8_allmax(rest);
-            cur = group8_allmax(cur);
-#pragma unroll
-            for (int k = 0; k < 4; k++) cur = ops.value(max_of(rest, cur), alpha_gamma, alpha, gamma);
-            if (my_step == (unsigned)(gi * 4 + 3)) lds_store<QT>(wo, cur);
-            __builtin_amdgcn_wave_barrier();
-            continue;
+        for (int gi = 0; gi < 8; gi++) {
+            if (gi * 4 >= nsub) break;
+            replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
+                                                alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
         }
-        const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
-        int lo = max(first, 0);
-        if (lo >= nv) continue;
-        do {
-            const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
-            QT m = lds_load<QT>(ad[0]);
-#pragma unroll
-            for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(ad[i]));
-            m = group8_allmax(m);
-            const QT val = ops.value(m, alpha_gamma, alpha, gamma);
-            if ((unsigned)(my_step - (unsigned)(gi * 4 + lo)) < (unsigned)(hi - lo)) lds_store<QT>(wo, val);
-            __builtin_amdgcn_wave_barrier();
-            lo = hi;
-        } while (lo < nv);
+    } else {
+        for (int gi = 0; gi * 4 < nsub; gi++)
+            replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
+                                                alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
     }
 }
 
@@ -363,6 +381,7 @@ __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool kUnrollReplay = sizeof(QT) == 4 && !NOISE && NSEG <= 2;     // the headline shapes
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // A training cycle = epk episodes played against frozen tables (the replay buffer reaches min_memory
@@ -505,12 +524,23 @@ k_wave_episodes(const WaveArgs a) {
                 const QT* r1 = tab1 + row * A;
                 QT b0 = r0[0], b1 = r1[0];
                 uint32_t i0 = 0, i1 = 0;
-                if (!(kAblate & 16))
+                if (kAblate & 16) {
+                } else if (A == 21) {
+                    // the reference's example configs: constant trip count, so the column numbers are inline
+                    // constants of the selects (no index register, no loop control): 7 instructions per column pair
+#pragma unroll
+                    for (int j = 1; j < 21; j++) {
+                        const QT v0 = r0[j], v1 = r1[j];
+                        if (v0 > b0) { b0 = v0; i0 = j; }
+                        if (v1 > b1) { b1 = v1; i1 = j; }
+                    }
+                } else {
 #pragma unroll 4
-                for (int j = 1; j < A; j++) {
-                    const QT v0 = r0[j], v1 = r1[j];
-                    if (v0 > b0) { b0 = v0; i0 = j; }
-                    if (v1 > b1) { b1 = v1; i1 = j; }
+                    for (int j = 1; j < A; j++) {
+                        const QT v0 = r0[j], v1 = r1[j];
+                        if (v0 > b0) { b0 = v0; i0 = j; }
+                        if (v1 > b1) { b1 = v1; i1 = j; }
+                    }
                 }
                 if (kAblate & 16) { i0 = (uint32_t)(lane * 5) % (uint32_t)A; i1 = (uint32_t)(lane * 3) % (uint32_t)A; }
                 AM[k] = i0 | (i1 << 8);
@@ -781,7 +811,8 @@ k_wave_episodes(const WaveArgs a) {
                 const bool any_fixed = __ballot((P >> 31) != 0u) != 0ull;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    const int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
+                    int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
+                    asm volatile("" : "+s"(nsub));          // (as for the play loop: keeps the per-group tests scalar compares)
                     if (nsub <= 0) break;
                     BlockOps<QT> ops = make_ops(snap[seg], k, r0d, r1d, alpha_h);
                     ops.permute(perm_sel);                                   // step layout -> exec layout
@@ -789,7 +820,7 @@ k_wave_episodes(const WaveArgs a) {
                     // 3 row reads per lane cover 24 columns (fewer columns: clamped duplicates), 4 cover 32.
                     // The fixed-point path is compiled into a second copy of the loop, entered only when the
                     // segment has such a group: the common exploring-regime loop stays as tight as without it.
-#define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
+#define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_, kUnrollReplay && RDN_ == 3>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
                                                           ag_h, alpha_h, gamma_h, half != 0, seg * 64 + k * 32, replay_from)
                     if (A > 24)      { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
                     else if (A >= 3) { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
