@@ -580,7 +580,12 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t h = (uint32_t)(lane * 2654435761u) ^ eg;
                     rw = (h & 3u) | (((h >> 4) % (uint32_t)A) << 8) | (((h >> 12) % (uint32_t)A) << 16);
                 } else {
-                    const u32x4 x = draw(a.seed, gid, eg + (uint32_t)ep, st_in_ep, 0u);
+                    // the ten round keys are seed + r * constant: recomputed here by scalar adds (opaque seed) --
+                    // hoisted out of the episode loop they were twenty spilled SGPRs, a v_readlane each per use
+                    uint32_t seed_lo = (uint32_t)a.seed, seed_hi = (uint32_t)(a.seed >> 32);
+                    asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
+                    const uint64_t seed_here = ((uint64_t)seed_hi << 32) | seed_lo;
+                    const u32x4 x = draw(seed_here, gid, eg + (uint32_t)ep, st_in_ep, 0u);
                     const uint32_t ex0 = u01_32(x.x) < eps0 ? 1u : 0u;
                     const uint32_t ex1 = u01_32(x.z) < eps1 ? 2u : 0u;
                     rw = ex0 | ex1 | (__umulhi(x.y, (uint32_t)A) << 8) | (__umulhi(x.w, (uint32_t)A) << 16);
