@@ -93,8 +93,7 @@ __device__ __forceinline__ float group8_allmax(float v) {
         "s_nop 1\n\t"
         "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
-        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
         : "+v"(v));
     return v;
 }
@@ -103,6 +102,19 @@ __device__ __forceinline__ double group8_allmax(double v) {
     v = fmax(v, dpp_mov64<0x4E>(v));       // quad_perm [2,3,0,1]
     v = fmax(v, dpp_mov64<0x141>(v));      // row_half_mirror
     return v;
+}
+// LDS store by the lanes of `mask` only, as straight-line code: hipcc turns `if (cond) store` into
+// saveexec + skip branch + store + branch back; the mask is never empty here, so EXEC is simply swapped around
+// the store.
+__device__ __forceinline__ void store_where(unsigned long long mask, unsigned addr, float v) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b32 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_where(unsigned long long mask, unsigned addr, double v) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
 }
 __device__ __forceinline__ float max_of(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double max_of(double a, double b) { return fmax(a, b); }
@@ -335,6 +347,7 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
     const uint32_t cuts = (((sP >> 28) & 7u) << 1) | (1u << nv);       // bit j: a pass ends before transition j
     int lo = max(first, 0);
     if (lo >= nv) return;
+    const unsigned d_in_group = my_step - (unsigned)(gi * 4);            // 0..3 in the lanes that hold this group's transitions
     do {
         const int hi = lo + 1 + __builtin_ctz(cuts >> (lo + 1));
         QT m = lds_load<QT>(ad[0]);
@@ -342,7 +355,7 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
         for (int i = 1; i < RDN; i++) m = max_of(m, lds_load<QT>(ad[i]));
         m = group8_allmax(m);
         const QT val = ops.value(m, alpha_gamma, alpha, gamma);
-        if ((unsigned)(my_step - (unsigned)(gi * 4 + lo)) < (unsigned)(hi - lo)) lds_store<QT>(wo, val);
+        store_where(__ballot((unsigned)(d_in_group - (unsigned)lo) < (unsigned)(hi - lo)), wo, val);
         __builtin_amdgcn_wave_barrier();
         lo = hi;
     } while (lo < nv);
@@ -356,6 +369,15 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
                                              int block_step0, int replay_from) {
     if (kAblate & 1) { ops.keep(); asm volatile("" :: "v"(wo), "v"(P)); return; }
     if (UNROLL) {
+        if (nsub == 32) {
+            // a full block (three of the four blocks of a 100-step episode): every "is this group / transition
+            // inside the block" test folds away
+#pragma unroll
+            for (int gi = 0; gi < 8; gi++)
+                replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, 32, ops, wo, rd_base, row_shift, my_step, row_bytes,
+                                                    alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
+            return;
+        }
 #pragma unroll
         for (int gi = 0; gi < 8; gi++) {
             if (gi * 4 >= nsub) break;
