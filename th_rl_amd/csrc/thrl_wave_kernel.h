@@ -673,7 +673,7 @@ k_wave_episodes(const WaveArgs a) {
                 // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step; the state each step was
                 // played in is recorded in lane t of sq.
                 uint32_t sq = 0, sq_tail = 0;          // sq: two states per lane (full groups); sq_tail: one per lane
-                auto chain4 = [&](auto t0c, const uint32_t (&tab)[4][NRSEG]) {
+                auto chain4 = [&](auto t0c, const int n, const uint32_t (&tab)[4][NRSEG]) {      // n: steps in the segment
                     constexpr int t0 = decltype(t0c)::value;
                     if (kAblate & 2) {
                         asm volatile("" :: "v"(tab[0][0]), "v"(tab[1][0]), "v"(tab[2][0]), "v"(tab[3][0]));
@@ -710,17 +710,21 @@ k_wave_episodes(const WaveArgs a) {
                 // Fully unrolled over the segment's 16 groups of four steps (step numbers become immediates: no
                 // index arithmetic or loop control per step; a group past the segment's end costs one scalar test).
                 build4(0, ta);
-#define THRL_PLAY2(G)                                                                        \
-                if ((G) * 4 < n) {                                                           \
-                    if ((G) * 4 + 4 < n) build4((G) * 4 + 4, tb);                            \
-                    chain4(std::integral_constant<int, (G) * 4>(), ta);                      \
-                    if ((G) * 4 + 4 < n) {                                                   \
-                        if ((G) * 4 + 8 < n) build4((G) * 4 + 8, ta);                        \
-                        chain4(std::integral_constant<int, (G) * 4 + 4>(), tb);              \
+#define THRL_PLAY2(G, N_)                                                                    \
+                if ((G) * 4 < (N_)) {                                                        \
+                    if ((G) * 4 + 4 < (N_)) build4((G) * 4 + 4, tb);                         \
+                    chain4(std::integral_constant<int, (G) * 4>(), (N_), ta);                \
+                    if ((G) * 4 + 4 < (N_)) {                                                \
+                        if ((G) * 4 + 8 < (N_)) build4((G) * 4 + 8, ta);                     \
+                        chain4(std::integral_constant<int, (G) * 4 + 4>(), (N_), tb);        \
                     }                                                                        \
                 }
-                THRL_PLAY2(0) THRL_PLAY2(2) THRL_PLAY2(4) THRL_PLAY2(6)
-                THRL_PLAY2(8) THRL_PLAY2(10) THRL_PLAY2(12) THRL_PLAY2(14)
+#define THRL_PLAY16(N_)                                                                      \
+                THRL_PLAY2(0, N_) THRL_PLAY2(2, N_) THRL_PLAY2(4, N_) THRL_PLAY2(6, N_)      \
+                THRL_PLAY2(8, N_) THRL_PLAY2(10, N_) THRL_PLAY2(12, N_) THRL_PLAY2(14, N_)
+                // a full segment (the first of a 100-step episode) runs a copy without any of the tests
+                if (n == 64) { THRL_PLAY16(64) } else { THRL_PLAY16(n) }
+#undef THRL_PLAY16
 #undef THRL_PLAY2
                 {   // unpack: lanes below the last full group of the hand-scheduled path hold two states per even lane
                     const int packed_end = (NRSEG == 1 && !(kAblate & 2)) ? (n & ~3) : 0;
