@@ -90,6 +90,9 @@ int launch_wave_f64_plain(const WaveArgs& a, int grid, int block, size_t lds_byt
 int launch_wave_f64_noise(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f64_sweep(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 // CYCLE = true variants: training cycles of several episodes and / or transitions dropped from the deque
+// GREEDY: the play loop skips the per-step table of groups of four steps in which nobody explores
+int launch_wave_f32_plain_greedy(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_wave_f64_plain_greedy(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f32_plain_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f32_noise_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_wave_f64_plain_cycle(const WaveArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);

@@ -61,19 +61,27 @@ int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+constexpr double kGreedyEps = 0.17;
+
 int launch_wave(const WaveArgs& a, int q_dtype, int grid, int block, size_t lds, hipStream_t s) {
     const bool sweep = a.sw_gamma || a.sw_alpha || a.sw_eps_end || a.sw_eps_step || a.sw_eps || a.sw_noise_prob;
     const int variant = sweep ? 2 : (a.env.noise_prob > 0.0 ? 1 : 0);     // sweep: noise code present, taken per game
     const bool cycle = a.epk > 1 || a.replay_from > 0;                    // (never together with sweeps: thrl_api.hip)
+    // Once both agents explore in fewer than ~17 % of their steps, more than a quarter of the groups of four steps
+    // are all-greedy and the variant that skips their table build is the faster one (it pays two scalar
+    // instructions per group; break-even (1 - eps)^8 = 6/26).  Same results either way.
+    const bool greedy = !cycle && variant == 0 && a.eps[0][0] <= kGreedyEps && a.eps[0][1] <= kGreedyEps;
     if (q_dtype == 1) {
         switch (variant) {
-            case 0: return cycle ? launch_wave_f64_plain_cycle(a, grid, block, lds, s) : launch_wave_f64_plain(a, grid, block, lds, s);
+            case 0: return cycle ? launch_wave_f64_plain_cycle(a, grid, block, lds, s)
+                          : greedy ? launch_wave_f64_plain_greedy(a, grid, block, lds, s) : launch_wave_f64_plain(a, grid, block, lds, s);
             case 1: return cycle ? launch_wave_f64_noise_cycle(a, grid, block, lds, s) : launch_wave_f64_noise(a, grid, block, lds, s);
             default: return launch_wave_f64_sweep(a, grid, block, lds, s);
         }
     }
     switch (variant) {
-        case 0: return cycle ? launch_wave_f32_plain_cycle(a, grid, block, lds, s) : launch_wave_f32_plain(a, grid, block, lds, s);
+        case 0: return cycle ? launch_wave_f32_plain_cycle(a, grid, block, lds, s)
+                      : greedy ? launch_wave_f32_plain_greedy(a, grid, block, lds, s) : launch_wave_f32_plain(a, grid, block, lds, s);
         case 1: return cycle ? launch_wave_f32_noise_cycle(a, grid, block, lds, s) : launch_wave_f32_noise(a, grid, block, lds, s);
         default: return launch_wave_f32_sweep(a, grid, block, lds, s);
     }

@@ -398,7 +398,7 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
 // its larger row window leaves room for fewer waves, so the register budget is relaxed.
 // SWEEP: per-game hyper-parameter arrays (thrl_buffers.sweep_*); compiled only together with NOISE
 // so the headline variant carries none of that state.
-template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE>
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE, bool GREEDY = false>
 __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
 k_wave_episodes(const WaveArgs a) {
@@ -568,6 +568,10 @@ k_wave_episodes(const WaveArgs a) {
                 AM[k] = i0 | (i1 << 8);
                 R[k] = (i0 * (uint32_t)A * 2u) | (i1 << 17);
             }
+            // "next row if a step in which NOBODY explores is played in row r": one table for the whole episode
+            // (the tables are frozen during play).  A group of four such steps needs no per-step table at all --
+            // late in training that is nearly every group.
+            const uint32_t Gt = (GREEDY && NRSEG == 1) ? (uint32_t)lds_load<unsigned short>(halves_sum(R[0]) + lut_ns_lds) : 0u;
 
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
@@ -637,6 +641,17 @@ k_wave_episodes(const WaveArgs a) {
                 const uint32_t Kv = lut_ns_lds + 2u * (((rw & 1u) ? ((rw >> 8) & 0xFFu) * (uint32_t)A : 0u) +
                                                       ((rw & 2u) ? ((rw >> 16) & 0xFFu) : 0u));
                 const unsigned long long noisy_steps = NOISE ? __ballot((rw & 4u) != 0u) : 0ull;   // scalar: no per-step readlane
+                // bit 4g: group g (steps 4g..4g+3) has a step that needs its own table (somebody explores, the step is
+                // noisy, or it lies beyond the segment's end)
+                unsigned long long busy_groups = 0ull;
+                if (GREEDY && NRSEG == 1) {
+                    busy_groups = __ballot((rw & (NOISE ? 7u : 3u)) != 0u || seg * 64 + lane >= T);
+                    busy_groups |= busy_groups >> 1;
+                    busy_groups |= busy_groups >> 2;
+                }
+                // GREEDY variants (launched once epsilon is small, thrl_wave.hip): the play loop looks at those bits,
+                // two scalar instructions per group, and skips the table build of the all-greedy groups
+                constexpr bool greedy_copy = GREEDY && NRSEG == 1 && !(kAblate & 6);
                 // Phase 1 (off the serial chain, lane = ROW): nsr_t[r] for one step; its LDS gather does
                 // not depend on the current state.
                 auto build = [&](int t, uint32_t (&out)[NRSEG], bool may_be_noisy) {
@@ -673,7 +688,7 @@ k_wave_episodes(const WaveArgs a) {
                 // Phase 2 (the chain): s <- nsr_t[s], one v_readlane per step; the state each step was
                 // played in is recorded in lane t of sq.
                 uint32_t sq = 0, sq_tail = 0;          // sq: two states per lane (full groups); sq_tail: one per lane
-                auto chain4 = [&](auto t0c, const int n, const uint32_t (&tab)[4][NRSEG]) {      // n: steps in the segment
+                auto chain4 = [&](auto t0c, const int n, const uint32_t (&tab)[4][NRSEG], const bool all_greedy = false) {   // n: steps in the segment
                     constexpr int t0 = decltype(t0c)::value;
                     if (kAblate & 2) {
                         asm volatile("" :: "v"(tab[0][0]), "v"(tab[1][0]), "v"(tab[2][0]), "v"(tab[3][0]));
@@ -682,7 +697,8 @@ k_wave_episodes(const WaveArgs a) {
                     }
                     if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
                         s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
-                        chain_group<t0>(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0]);
+                        if (all_greedy) chain_group<t0>(sq, s, Gt, Gt, Gt, Gt);
+                        else chain_group<t0>(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0]);
                         return;
                     }
                     s = __builtin_amdgcn_readfirstlane(s);
@@ -709,7 +725,6 @@ k_wave_episodes(const WaveArgs a) {
                 };
                 // Fully unrolled over the segment's 16 groups of four steps (step numbers become immediates: no
                 // index arithmetic or loop control per step; a group past the segment's end costs one scalar test).
-                build4(0, ta);
 #define THRL_PLAY2(G, N_)                                                                    \
                 if ((G) * 4 < (N_)) {                                                        \
                     if ((G) * 4 + 4 < (N_)) build4((G) * 4 + 4, tb);                         \
@@ -722,8 +737,32 @@ k_wave_episodes(const WaveArgs a) {
 #define THRL_PLAY16(N_)                                                                      \
                 THRL_PLAY2(0, N_) THRL_PLAY2(2, N_) THRL_PLAY2(4, N_) THRL_PLAY2(6, N_)      \
                 THRL_PLAY2(8, N_) THRL_PLAY2(10, N_) THRL_PLAY2(12, N_) THRL_PLAY2(14, N_)
+                // the same with the all-greedy groups skipping their table build (g0: the group the chain runs next)
+#define THRL_PLAY2G(G, N_)                                                                   \
+                if ((G) * 4 < (N_)) {                                                        \
+                    const bool g1 = !((busy_groups >> ((G) * 4 + 4)) & 1ull);                \
+                    if ((G) * 4 + 4 < (N_) && !g1) build4((G) * 4 + 4, tb);                  \
+                    chain4(std::integral_constant<int, (G) * 4>(), (N_), ta, g0);            \
+                    if ((G) * 4 + 4 < (N_)) {                                                \
+                        g0 = (G) * 4 + 8 < 64 && !((busy_groups >> (((G) * 4 + 8) & 63)) & 1ull);   \
+                        if ((G) * 4 + 8 < (N_) && !g0) build4((G) * 4 + 8, ta);              \
+                        chain4(std::integral_constant<int, (G) * 4 + 4>(), (N_), tb, g1);    \
+                    }                                                                        \
+                }
+#define THRL_PLAY16G(N_)                                                                         \
+                THRL_PLAY2G(0, N_) THRL_PLAY2G(2, N_) THRL_PLAY2G(4, N_) THRL_PLAY2G(6, N_)      \
+                THRL_PLAY2G(8, N_) THRL_PLAY2G(10, N_) THRL_PLAY2G(12, N_) THRL_PLAY2G(14, N_)
                 // a full segment (the first of a 100-step episode) runs a copy without any of the tests
-                if (n == 64) { THRL_PLAY16(64) } else { THRL_PLAY16(n) }
+                if (greedy_copy) {
+                    bool g0 = !(busy_groups & 1ull);
+                    if (!g0) build4(0, ta);
+                    if (n == 64) { THRL_PLAY16G(64) } else { THRL_PLAY16G(n) }
+                } else {
+                    build4(0, ta);
+                    if (n == 64) { THRL_PLAY16(64) } else { THRL_PLAY16(n) }
+                }
+#undef THRL_PLAY16G
+#undef THRL_PLAY2G
 #undef THRL_PLAY16
 #undef THRL_PLAY2
                 {   // unpack: lanes below the last full group of the hand-scheduled path hold two states per even lane
@@ -976,9 +1015,9 @@ k_wave_episodes(const WaveArgs a) {
     a.partial[(size_t)wave_gid * 128 + 64 + lane] = acc_hi;
 }
 
-template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE>
+template <typename QT, int NSEG, int NRSEG, bool NOISE, bool SWEEP, bool CYCLE, bool GREEDY = false>
 static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    auto kern = k_wave_episodes<QT, NSEG, NRSEG, NOISE, SWEEP, CYCLE>;
+    auto kern = k_wave_episodes<QT, NSEG, NRSEG, NOISE, SWEEP, CYCLE, GREEDY>;
     if (lds > 64 * 1024) {                       // beyond the default dynamic-LDS limit (float64 tables: one block per CU)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -988,23 +1027,23 @@ static int launch_wave_t(const WaveArgs& a, int grid, int block, size_t lds, hip
     return (int)hipGetLastError();
 }
 
-template <typename QT, bool NOISE, bool SWEEP, bool CYCLE>
+template <typename QT, bool NOISE, bool SWEEP, bool CYCLE, bool GREEDY = false>
 static int launch_wave_n(const WaveArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T * a.epk + 63) / 64;
     const int nrseg = (a.win_rows + 2 + 63) / 64;
     if (nrseg == 1) {
         switch (nseg) {
-            case 1: return launch_wave_t<QT, 1, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<QT, 2, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<QT, 3, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<QT, 4, 1, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<QT, 1, 1, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 1, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 1, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 1, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
         }
     } else if (nrseg == 2) {
         switch (nseg) {
-            case 1: return launch_wave_t<QT, 1, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 2: return launch_wave_t<QT, 2, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 3: return launch_wave_t<QT, 3, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
-            case 4: return launch_wave_t<QT, 4, 2, NOISE, SWEEP, CYCLE>(a, grid, block, lds, s);
+            case 1: return launch_wave_t<QT, 1, 2, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 2: return launch_wave_t<QT, 2, 2, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 3: return launch_wave_t<QT, 3, 2, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
+            case 4: return launch_wave_t<QT, 4, 2, NOISE, SWEEP, CYCLE, GREEDY>(a, grid, block, lds, s);
         }
     }
     return -1;
