@@ -116,6 +116,9 @@ __device__ __forceinline__ void store_where(unsigned long long mask, unsigned ad
     asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
                  : "=&s"(save) : "s"(mask), "v"(addr), "v"(v) : "memory");
 }
+// the value of the lane 8 further on in the same 16-lane row (row_ror:8): swaps the two 8-lane groups of a row
+__device__ __forceinline__ float dpp_ror8(float v) { return __builtin_bit_cast(float, dpp_mov32<0x128>(__builtin_bit_cast(uint32_t, v))); }
+__device__ __forceinline__ double dpp_ror8(double v) { return dpp_mov64<0x128>(v); }
 __device__ __forceinline__ float max_of(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double max_of(double a, double b) { return fmax(a, b); }
 
@@ -311,7 +314,7 @@ template <> struct HP<double> {
 //              is four dependent (row max, TD value) pairs on one cell; here the row is read once, split
 //              into "the cell" and "max of the rest", and the four pairs run in registers: one store.
 //   ops, wo  operands / LDS store address of transition 4*(lane&7) + ((lane>>3)&3) ("exec layout")
-template <typename QT, int RDN, bool FIXED_POINTS>
+template <typename QT, int RDN, bool FIXED_POINTS, bool PER2>
 __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              unsigned rd_base, unsigned row_shift, unsigned my_step,
                                              unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
@@ -325,6 +328,35 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
     unsigned ad[RDN];                                       // this lane's columns of its transition's next-state row
 #pragma unroll
     for (int i = 0; i < RDN; i++) ad[i] = rd_base + rowoff + (unsigned)(i * sizeof(QT));
+    if (FIXED_POINTS && PER2 && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256) && (sP & 0x7Fu) != ((sP >> 7) & 0x7Fu)) {
+        // PERIOD-2 CYCLE (A, B, A, B): A is played in row sA and leads to row sB, B leads back.  Serially that is
+        // four dependent (row max, TD value) pairs: each transition reads the row its predecessor just wrote.
+        // Here groups 0/2 (the A's) read row sB once and split it into "the cell B writes" and the rest, groups
+        // 1/3 do the same for row sA and A's cell, and the four values run in registers, each handed to the
+        // neighbouring 8-lane group by one DPP rotate: y0 = A(max row sB), y1 = B(max(rest sA, y0)),
+        // y2 = A(max(rest sB, y1)), y3 = B(max(rest sA, y2)); the cells end as y2 / y3.
+        // exec layout: transition 4*gi + i sits in lanes 8*i + gi / 32 + 8*i + gi
+        const unsigned ca0 = readlane_u(wo, gi), ca1 = readlane_u(wo, 32 + gi);
+        const unsigned cb0 = readlane_u(wo, 8 + gi), cb1 = readlane_u(wo, 40 + gi);
+        const bool odd = (my_step & 1u) != 0u;                  // my_step & 3 = this lane's 8-lane group
+        const unsigned cell = odd ? (upper_half ? ca1 : ca0) : (upper_half ? cb1 : cb0);
+        QT rest = -(QT)INFINITY, m = -(QT)INFINITY;
+#pragma unroll
+        for (int i = 0; i < RDN; i++) {
+            const QT e = lds_load<QT>(ad[i]);
+            m = max_of(m, e);
+            rest = max_of(rest, ad[i] == cell ? -(QT)INFINITY : e);
+        }
+        rest = group8_allmax(rest);
+        m = group8_allmax(m);
+        const QT y0 = ops.value(m, alpha_gamma, alpha, gamma);
+        const QT y1 = ops.value(max_of(rest, dpp_ror8(y0)), alpha_gamma, alpha, gamma);
+        const QT y2 = ops.value(max_of(rest, dpp_ror8(y1)), alpha_gamma, alpha, gamma);
+        const QT y3 = ops.value(max_of(rest, dpp_ror8(y2)), alpha_gamma, alpha, gamma);
+        store_where(__ballot((unsigned)(my_step - (unsigned)(gi * 4 + 2)) < 2u), wo, odd ? y3 : y2);
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     if (FIXED_POINTS && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256)) {
         // the rewritten cell, per agent: lanes gi / 32+gi hold transition 4*gi's store address
         const unsigned c0 = readlane_u(wo, gi), c1 = readlane_u(wo, 32 + gi);
@@ -362,7 +394,7 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
 }
 // UNROLL: the block's 8 groups as straight-line code (group numbers become immediates, no loop control):
 // the headline variants; the others keep the loop (code size; hipcc 7.2 also fails on the unrolled noise variants).
-template <typename QT, int RDN, bool FIXED_POINTS, bool UNROLL>
+template <typename QT, int RDN, bool FIXED_POINTS, bool UNROLL, bool PER2>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              unsigned rd_base, unsigned row_shift, unsigned my_step,
                                              unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma, bool upper_half,
@@ -374,19 +406,19 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
             // inside the block" test folds away
 #pragma unroll
             for (int gi = 0; gi < 8; gi++)
-                replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, 32, ops, wo, rd_base, row_shift, my_step, row_bytes,
+                replay_group<QT, RDN, FIXED_POINTS, PER2>(gi, P, lane_base, 32, ops, wo, rd_base, row_shift, my_step, row_bytes,
                                                     alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
             return;
         }
 #pragma unroll
         for (int gi = 0; gi < 8; gi++) {
             if (gi * 4 >= nsub) break;
-            replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
+            replay_group<QT, RDN, FIXED_POINTS, PER2>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
                                                 alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
         }
     } else {
         for (int gi = 0; gi * 4 < nsub; gi++)
-            replay_group<QT, RDN, FIXED_POINTS>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
+            replay_group<QT, RDN, FIXED_POINTS, PER2>(gi, P, lane_base, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes,
                                                 alpha_gamma, alpha, gamma, upper_half, block_step0, replay_from);
     }
 }
@@ -872,7 +904,12 @@ k_wave_episodes(const WaveArgs a) {
                     const uint32_t c1 = h1 & 1u;
                     const uint32_t c2 = ((h2 >> 1) & 1u) | ((c1 ^ 1u) & h2 & 1u);
                     const uint32_t c3 = ((h3 >> 2) & 1u) | ((c2 ^ 1u) & (((h3 >> 1) & 1u) | ((c1 ^ 1u) & h3 & 1u)));
-                    const uint32_t same4 = (b0 == b1 && b1 == b2 && b2 == b3 && (b0 >> 24) == ((b0 >> 16) & 0xFFu)) ? 1u : 0u;
+                    // bit 31: the group runs in registers (replay_group): four identical transitions that stay in
+                    // their row, or a period-2 cycle A, B, A, B between two different rows (told apart by rows 0 / 1)
+                    // (the period-2 path only in the GREEDY variants: while the agents explore there are no such groups)
+                    const uint32_t same4 = ((b0 == b1 && b1 == b2 && b2 == b3 && (b0 >> 24) == ((b0 >> 16) & 0xFFu)) ||
+                                            (GREEDY && b0 == b2 && b1 == b3 && (b0 >> 24) == ((b1 >> 16) & 0xFFu) &&
+                                             (b1 >> 24) == ((b0 >> 16) & 0xFFu) && (b0 >> 24) != (b1 >> 24))) ? 1u : 0u;
                     P = (b0 >> 24) | ((b1 >> 24) << 7) | ((b2 >> 24) << 14) | ((b3 >> 24) << 21) |
                         ((c1 | (c2 << 1) | (c3 << 2)) << 28) | (same4 << 31);
                 }
@@ -890,7 +927,7 @@ k_wave_episodes(const WaveArgs a) {
                     // 3 row reads per lane cover 24 columns (fewer columns: clamped duplicates), 4 cover 32.
                     // The fixed-point path is compiled into a second copy of the loop, entered only when the
                     // segment has such a group: the common exploring-regime loop stays as tight as without it.
-#define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_, kUnrollReplay && RDN_ == 3>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
+#define THRL_REPLAY(RDN_, FP_) replay_block<QT, RDN_, FP_, kUnrollReplay && RDN_ == 3, GREEDY>(P, k * 32, nsub, ops, wo, rd_base, row_shift, my_step, row_bytes, \
                                                           ag_h, alpha_h, gamma_h, half != 0, seg * 64 + k * 32, replay_from)
                     if (A > 24)      { if (any_fixed) THRL_REPLAY(4, true); else THRL_REPLAY(4, false); }
                     else if (A >= 3) { if (any_fixed) THRL_REPLAY(3, true); else THRL_REPLAY(3, false); }
