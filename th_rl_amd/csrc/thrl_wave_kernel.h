@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool kUnrollReplay = sizeof(QT) == 4 && !NOISE && NSEG <= 2;     // the headline shapes
+    constexpr bool kUnrollReplay = !NOISE && NSEG <= 2;     // the headline shapes (float32 and float64)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // A training cycle = epk episodes played against frozen tables (the replay buffer reaches min_memory
