@@ -209,6 +209,43 @@ __device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, u
     s = s4;
 }
 
+// The same for four steps in which nobody explores: with G = "next row of a greedy step" composed with itself
+// (g1 = G, g2 = G.G, g3 = G.G.G, g4 = G^4, built once per episode) the four reads all use the group's entry
+// state, so only the first waits for it.
+template <int T0>
+__device__ __forceinline__ void chain_group_greedy(uint32_t& sq, int& s, uint32_t g1, uint32_t g2, uint32_t g3, uint32_t g4) {
+    int s1, s2, s3, s4, pk;
+    asm volatile(
+        "s_nop 3\n\t"
+        "v_readlane_b32 %1, %7, %6\n\t"
+        "v_readlane_b32 %2, %8, %6\n\t"
+        "v_readlane_b32 %3, %9, %6\n\t"
+        "v_readlane_b32 %4, %10, %6\n\t"
+        "s_pack_ll_b32_b16 %5, %6, %1\n\t"
+        "v_writelane_b32 %0, %5, %11\n\t"
+        "s_pack_ll_b32_b16 %5, %2, %3\n\t"
+        "v_writelane_b32 %0, %5, %12"
+        : "+v"(sq), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(pk)
+        : "s"(s), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "n"(T0), "n"(T0 + 2)
+        : "scc");
+    s = s4;
+}
+
+template <bool ON> struct GreedyTables {            // (nothing in the variants that do not use them)
+    __device__ __forceinline__ void build(unsigned) {}
+    template <int T0> __device__ __forceinline__ void chain(uint32_t&, int&) const {}
+};
+template <> struct GreedyTables<true> {
+    uint32_t g1, g2, g3, g4;
+    __device__ __forceinline__ void build(unsigned lut_addr) {
+        g1 = (uint32_t)lds_load<unsigned short>(lut_addr);
+        g2 = bperm((g1 & 63u) << 2, g1);
+        g3 = bperm((g2 & 63u) << 2, g1);
+        g4 = bperm((g2 & 63u) << 2, g2);
+    }
+    template <int T0> __device__ __forceinline__ void chain(uint32_t& sq, int& s) const { chain_group_greedy<T0>(sq, s, g1, g2, g3, g4); }
+};
+
 // value of a lane-indexed-by-row register pair at (uniform) row s
 template <int NRSEG>
 __device__ __forceinline__ uint32_t read_row(const uint32_t (&r)[NRSEG], int s) {
@@ -603,7 +640,8 @@ k_wave_episodes(const WaveArgs a) {
             // "next row if a step in which NOBODY explores is played in row r": one table for the whole episode
             // (the tables are frozen during play).  A group of four such steps needs no per-step table at all --
             // late in training that is nearly every group.
-            const uint32_t Gt = (GREEDY && NRSEG == 1) ? (uint32_t)lds_load<unsigned short>(halves_sum(R[0]) + lut_ns_lds) : 0u;
+            GreedyTables<GREEDY && NRSEG == 1> gt;          // + G composed with itself: rows after 2, 3, 4 greedy steps
+            gt.build(halves_sum(R[0]) + lut_ns_lds);
 
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
@@ -729,7 +767,7 @@ k_wave_episodes(const WaveArgs a) {
                     }
                     if (NRSEG == 1 && t0 + 4 <= n) {            // full group, one-register tables: hand-scheduled steps
                         s = __builtin_amdgcn_readfirstlane(s);      // "s" operands must be provably uniform
-                        if (all_greedy) chain_group<t0>(sq, s, Gt, Gt, Gt, Gt);
+                        if (GREEDY && all_greedy) gt.template chain<t0>(sq, s);
                         else chain_group<t0>(sq, s, tab[0][0], tab[1][0], tab[2][0], tab[3][0]);
                         return;
                     }
