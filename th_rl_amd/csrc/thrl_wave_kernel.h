@@ -361,10 +361,11 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
     if (first >= 4) return;
     const uint32_t sP = readlane_u(P, lane_base + gi * 4);
     const int nv = min(4, nsub - gi * 4);
-    const unsigned rowoff = __umul24((sP >> row_shift) & 0x7Fu, row_bytes);
+    unsigned ad0;                                           // row * row_bytes + this lane's first column: one v_mad_u32_u24
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(ad0) : "v"((sP >> row_shift) & 0x7Fu), "s"(row_bytes), "v"(rd_base));
     unsigned ad[RDN];                                       // this lane's columns of its transition's next-state row
 #pragma unroll
-    for (int i = 0; i < RDN; i++) ad[i] = rd_base + rowoff + (unsigned)(i * sizeof(QT));
+    for (int i = 0; i < RDN; i++) ad[i] = ad0 + (unsigned)(i * sizeof(QT));
     if (FIXED_POINTS && PER2 && (sP >> 31) && nv == 4 && first <= 0 && !(kAblate & 256) && (sP & 0x7Fu) != ((sP >> 7) & 0x7Fu)) {
         // PERIOD-2 CYCLE (A, B, A, B): A is played in row sA and leads to row sB, B leads back.  Serially that is
         // four dependent (row max, TD value) pairs: each transition reads the row its predecessor just wrote.
