@@ -183,28 +183,26 @@ __device__ __forceinline__ uint32_t halves_sum(uint32_t x) {
 // four states the steps were played in recorded TWO PER LANE (lane t0: s_t0 | s_t0+1 << 16, lane t0+2:
 // s_t0+2 | s_t0+3 << 16; the caller unpacks lane-parallel) -- 6 vector instructions per group instead of 8.
 // Hand-placed wait states (hipcc does not look inside asm): a v_readlane whose lane select was written by
-// a VALU (the previous v_readlane) needs 4 wait states; the s_mov / s_add of M0, the s_pack and the
-// v_writelane fill them where they can, s_nop pads the rest.  v_writelane needs 1 after M0 changes.
+// a VALU (the previous v_readlane) needs 4 wait states; the s_pack and the v_writelane (lane number as an
+// immediate: the step numbers are compile-time constants) fill them where they can, s_nop pads the rest.
 template <int T0>
 __device__ __forceinline__ void chain_group(uint32_t& sq, int& s, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3) {
     int s1, s2, s3, s4, pk;
     asm volatile(
         "s_nop 3\n\t"
         "v_readlane_b32 %1, %7, %6\n\t"
-        "s_mov_b32 m0, %11\n\t"
-        "s_nop 2\n\t"
-        "v_readlane_b32 %2, %8, %1\n\t"
         "s_pack_ll_b32_b16 %5, %6, %1\n\t"
-        "v_writelane_b32 %0, %5, m0\n\t"
+        "v_writelane_b32 %0, %5, %11\n\t"
         "s_nop 1\n\t"
+        "v_readlane_b32 %2, %8, %1\n\t"
+        "s_nop 3\n\t"
         "v_readlane_b32 %3, %9, %2\n\t"
-        "s_add_u32 m0, m0, 2\n\t"
-        "s_nop 2\n\t"
-        "v_readlane_b32 %4, %10, %3\n\t"
         "s_pack_ll_b32_b16 %5, %2, %3\n\t"
-        "v_writelane_b32 %0, %5, m0"
+        "v_writelane_b32 %0, %5, %12\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 %4, %10, %3"
         : "+v"(sq), "=&s"(s1), "=&s"(s2), "=&s"(s3), "=&s"(s4), "=&s"(pk)
-        : "s"(s), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "n"(T0)
+        : "s"(s), "v"(n0), "v"(n1), "v"(n2), "v"(n3), "n"(T0), "n"(T0 + 2)
         : "scc");
     s = s4;
 }
