@@ -120,6 +120,29 @@ __device__ __forceinline__ void store_where(unsigned long long mask, unsigned ad
 __device__ __forceinline__ float dpp_ror8(float v) { return __builtin_bit_cast(float, dpp_mov32<0x128>(__builtin_bit_cast(uint32_t, v))); }
 __device__ __forceinline__ double dpp_ror8(double v) { return dpp_mov64<0x128>(v); }
 __device__ __forceinline__ float max_of(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double max_of(double a, double b);
+// max over each 32-lane half, result in every lane of the half: the 8-lane step above, the mirror of the 16-lane
+// row, then the two rows of the half exchanged by v_permlane16_swap
+__device__ __forceinline__ float half32_allmax(float v) {
+    v = group8_allmax(v);
+    v = fmaxf(v, __builtin_bit_cast(float, dpp_mov32<0x140>(__builtin_bit_cast(uint32_t, v))));      // row_mirror
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm("" : "+v"(b));
+    const v2u r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    const unsigned rx = r.x, ry = r.y;
+    return fmaxf(__builtin_bit_cast(float, rx), __builtin_bit_cast(float, ry));
+}
+__device__ __forceinline__ double half32_allmax(double v) {
+    v = group8_allmax(v);
+    v = fmax(v, dpp_mov64<0x140>(v));
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    unsigned lo2 = lo, hi2 = hi;
+    asm("" : "+v"(lo2), "+v"(hi2));
+    const v2u rl = __builtin_amdgcn_permlane16_swap(lo, lo2, false, false);
+    const v2u rh = __builtin_amdgcn_permlane16_swap(hi, hi2, false, false);
+    const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+    return fmax(__hiloint2double((int)rhx, (int)rlx), __hiloint2double((int)rhy, (int)rly));
+}
 __device__ __forceinline__ double max_of(double a, double b) { return fmax(a, b); }
 
 // Sum FOUR per-lane doubles over the 64 lanes in one pass ("transpose" reduction):
@@ -952,9 +975,54 @@ k_wave_episodes(const WaveArgs a) {
                 }
 
                 // ---- (e) replay (agents.py:68-76): live next_max, writes in transition order
+                // GREEDY variants: a converged game repeats ONE transition all segment long (a fixed point of the
+                // greedy play) or alternates between TWO (a period-2 cycle).  Then train_net's loop is a recurrence
+                // on one cell (two cells) per agent: the rows are read once, split into "the cell" and "the max of the
+                // rest", and the segment's transitions run in registers -- two vector instructions each.
+                bool seg_done = false;
+                if (GREEDY && !(kAblate & 257)) {
+                    const int nseg = min(64, T - seg * 64);
+                    const uint32_t w = act[seg];
+                    const uint32_t wA = readlane_u(w, 0), wB = readlane_u(w, nseg > 1 ? 1 : 0);
+                    const bool periodic = __ballot(lane < nseg && w != ((lane & 1) ? wB : wA)) == 0ull;
+                    const uint32_t sA = (wA >> 16) & 0xFFu, nA = wA >> 24, sB = (wB >> 16) & 0xFFu, nB = wB >> 24;
+                    const bool fixed1 = periodic && wA == wB && nA == sA;
+                    const bool cyc2 = periodic && nseg >= 2 && nA == sB && nB == sA && sA != sB;
+                    if (fixed1 || cyc2) {
+                        seg_done = true;
+                        const BlockOps<QT> ops0 = make_ops(snap[seg], 0, r0d, r1d, alpha_h);      // step layout: lane 32h + t
+                        BlockOps<QT> opsA = ops0, opsB = ops0;
+                        const unsigned selA = (unsigned)(lane & 32) << 2, selB = selA + 4u;
+                        opsA.permute(selA); opsB.permute(selB);
+                        const unsigned cellA = bperm(selA, woq.x), cellB = bperm(selB, woq.x);
+                        const unsigned tabh = half ? tab1_off : tab0_off;
+                        const unsigned colb = (unsigned)min(lane & 31, A - 1) * (unsigned)sizeof(QT);
+                        const unsigned adA = tabh + sA * row_bytes + colb, adB = tabh + sB * row_bytes + colb;
+                        QT restA = lds_load<QT>(adA), restB = lds_load<QT>(adB);
+                        QT curA = lds_load<QT>(cellA), curB = lds_load<QT>(cellB);
+                        restA = half32_allmax(adA == cellA ? -(QT)INFINITY : restA);
+                        if (fixed1) {
+                            for (int t = 0; t < nseg; t++) curA = opsA.value(max_of(restA, curA), ag_h, alpha_h, gamma_h);
+                        } else {
+                            restB = half32_allmax(adB == cellB ? -(QT)INFINITY : restB);
+                            int t = 0;
+                            for (; t + 1 < nseg; t += 2) {
+                                curA = opsA.value(max_of(restB, curB), ag_h, alpha_h, gamma_h);      // A: row sA -> row sB
+                                curB = opsB.value(max_of(restA, curA), ag_h, alpha_h, gamma_h);      // B: back
+                            }
+                            if (t < nseg) curA = opsA.value(max_of(restB, curB), ag_h, alpha_h, gamma_h);
+                        }
+                        if ((lane & 31) == 0) {
+                            lds_store<QT>(cellA, curA);
+                            if (!fixed1) lds_store<QT>(cellB, curB);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
                 const bool any_fixed = __ballot((P >> 31) != 0u) != 0ull;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
+                    if (GREEDY && seg_done) break;
                     int nsub = __builtin_amdgcn_readfirstlane(min(32, T - seg * 64 - k * 32));
                     asm volatile("" : "+s"(nsub));          // (as for the play loop: keeps the per-group tests scalar compares)
                     if (nsub <= 0) break;
