@@ -2,6 +2,7 @@
 // (thrl_wave_kernel.h): the payoff-LUT builder, the log reduction and the dispatch over the
 // compiled variants.  The variants themselves are instantiated in thrl_wave_f32.hip,
 // thrl_wave_f32n.hip and thrl_wave_f64*.hip (separate translation units: they compile in parallel).
+#include <cstdlib>
 #include "thrl_kernels.h"
 #include "thrl_wave_lut.h"
 
@@ -61,16 +62,22 @@ int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-constexpr double kGreedyEps = 0.17;
+// (THRL_GREEDY_EPS overrides the threshold for measurements; read once per process)
+static double greedy_eps() {
+    static const double v = [] { const char* e = getenv("THRL_GREEDY_EPS"); return e ? atof(e) : 0.05; }();
+    return v;
+}
 
 int launch_wave(const WaveArgs& a, int q_dtype, int grid, int block, size_t lds, hipStream_t s) {
     const bool sweep = a.sw_gamma || a.sw_alpha || a.sw_eps_end || a.sw_eps_step || a.sw_eps || a.sw_noise_prob;
     const int variant = sweep ? 2 : (a.env.noise_prob > 0.0 ? 1 : 0);     // sweep: noise code present, taken per game
     const bool cycle = a.epk > 1 || a.replay_from > 0;                    // (never together with sweeps: thrl_api.hip)
-    // Once both agents explore in fewer than ~17 % of their steps, more than a quarter of the groups of four steps
-    // are all-greedy and the variant that skips their table build is the faster one (it pays two scalar
-    // instructions per group; break-even (1 - eps)^8 = 6/26).  Same results either way.
-    const bool greedy = !cycle && variant == 0 && a.eps[0][0] <= kGreedyEps && a.eps[0][1] <= kGreedyEps;
+    // Once both agents explore in fewer than ~5 % of their steps the variant that skips the table build of all-greedy
+    // groups of four steps (and runs cyclic segments as recurrences) is the faster one: measured on trained tables
+    // (262,144 games), plain vs GREEDY: 3.20 vs 2.90e10 at epsilon 0.167, 3.15 vs 2.94 at 0.112, 3.07 vs 2.99 at 0.068,
+    // 3.01 vs 3.05 at 0.042 -- its per-group tests and cycle detection cost ~7 % while the agents still explore.
+    // Same results either way.
+    const bool greedy = !cycle && variant == 0 && a.eps[0][0] <= greedy_eps() && a.eps[0][1] <= greedy_eps();
     if (q_dtype == 1) {
         switch (variant) {
             case 0: return cycle ? launch_wave_f64_plain_cycle(a, grid, block, lds, s)
