@@ -482,6 +482,44 @@ __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub
     }
 }
 
+// A segment whose transitions repeat with period P (P different rows; transition j of the cycle is played in row
+// s_j, leads to row s_(j+1) and rewrites cell c_j of row s_j): train_net's serial loop (agents.py:68-76) as a
+// recurrence in registers.  cur[j] = live value of c_j, rest[j] = max of row s_j without c_j (the other cells of
+// the row do not change during the segment), so transition t = j (mod P) is
+//     cur[j] <- TD value(max(rest[j+1], cur[j+1]))        -- the same arithmetic, in the same order, as the passes.
+// ops0 / woq_x are in step layout (lane 32h + t = agent h, transition t < 32); W[j] = transition word of step j.
+template <typename QT, int P>
+__device__ __forceinline__ void cyclic_segment(const BlockOps<QT>& ops0, unsigned woq_x, const uint32_t (&W)[4], int nseg, int lane,
+                                               unsigned tabh, int A, unsigned row_bytes, QT alpha_gamma, QT alpha, QT gamma) {
+    BlockOps<QT> ops[P];
+    unsigned cell[P];
+    QT rest[P], cur[P];
+    const unsigned colb = (unsigned)min(lane & 31, A - 1) * (unsigned)sizeof(QT);
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const unsigned sel = (unsigned)((lane & 32) + j) << 2;
+        ops[j] = ops0;
+        ops[j].permute(sel);
+        cell[j] = bperm(sel, woq_x);
+        const unsigned ad = tabh + ((W[j] >> 16) & 0xFFu) * row_bytes + colb;
+        const QT v = lds_load<QT>(ad);
+        cur[j] = lds_load<QT>(cell[j]);
+        rest[j] = half32_allmax(ad == cell[j] ? -(QT)INFINITY : v);
+    }
+    int t = 0;
+    for (; t + P <= nseg; t += P) {
+#pragma unroll
+        for (int j = 0; j < P; j++) cur[j] = ops[j].value(max_of(rest[(j + 1) % P], cur[(j + 1) % P]), alpha_gamma, alpha, gamma);
+    }
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        if (t + j < nseg) cur[j] = ops[j].value(max_of(rest[(j + 1) % P], cur[(j + 1) % P]), alpha_gamma, alpha, gamma);
+    if ((lane & 31) == 0) {
+#pragma unroll
+        for (int j = 0; j < P; j++) lds_store<QT>(cell[j], cur[j]);
+    }
+}
+
 // LDS capacity allows 20 resident waves per CU for the headline window in float32, i.e. 5 per
 // SIMD: keep the register allocation at <= 96 VGPRs there (NSEG <= 2).  float64 tables are twice
 // the size (11 games per CU), so the register budget is relaxed there.
@@ -976,47 +1014,46 @@ k_wave_episodes(const WaveArgs a) {
 
                 // ---- (e) replay (agents.py:68-76): live next_max, writes in transition order
                 // GREEDY variants: a converged game repeats ONE transition all segment long (a fixed point of the
-                // greedy play) or alternates between TWO (a period-2 cycle).  Then train_net's loop is a recurrence
-                // on one cell (two cells) per agent: the rows are read once, split into "the cell" and "the max of the
-                // rest", and the segment's transitions run in registers -- two vector instructions each.
+                // greedy play) or cycles through TWO, THREE or FOUR.  Then train_net's loop is a recurrence on one cell
+                // per cycle position and agent: the rows are read once, split into "the cell" and "the max of the rest",
+                // and the segment's transitions run in registers -- two vector instructions each (cyclic_segment).
                 bool seg_done = false;
                 if (GREEDY && !(kAblate & 257)) {
                     const int nseg = min(64, T - seg * 64);
                     const uint32_t w = act[seg];
-                    const uint32_t wA = readlane_u(w, 0), wB = readlane_u(w, nseg > 1 ? 1 : 0);
-                    const bool periodic = __ballot(lane < nseg && w != ((lane & 1) ? wB : wA)) == 0ull;
-                    const uint32_t sA = (wA >> 16) & 0xFFu, nA = wA >> 24, sB = (wB >> 16) & 0xFFu, nB = wB >> 24;
-                    const bool fixed1 = periodic && wA == wB && nA == sA;
-                    const bool cyc2 = periodic && nseg >= 2 && nA == sB && nB == sA && sA != sB;
-                    if (fixed1 || cyc2) {
-                        seg_done = true;
-                        const BlockOps<QT> ops0 = make_ops(snap[seg], 0, r0d, r1d, alpha_h);      // step layout: lane 32h + t
-                        BlockOps<QT> opsA = ops0, opsB = ops0;
-                        const unsigned selA = (unsigned)(lane & 32) << 2, selB = selA + 4u;
-                        opsA.permute(selA); opsB.permute(selB);
-                        const unsigned cellA = bperm(selA, woq.x), cellB = bperm(selB, woq.x);
-                        const unsigned tabh = half ? tab1_off : tab0_off;
-                        const unsigned colb = (unsigned)min(lane & 31, A - 1) * (unsigned)sizeof(QT);
-                        const unsigned adA = tabh + sA * row_bytes + colb, adB = tabh + sB * row_bytes + colb;
-                        QT restA = lds_load<QT>(adA), restB = lds_load<QT>(adB);
-                        QT curA = lds_load<QT>(cellA), curB = lds_load<QT>(cellB);
-                        restA = half32_allmax(adA == cellA ? -(QT)INFINITY : restA);
-                        if (fixed1) {
-                            for (int t = 0; t < nseg; t++) curA = opsA.value(max_of(restA, curA), ag_h, alpha_h, gamma_h);
-                        } else {
-                            restB = half32_allmax(adB == cellB ? -(QT)INFINITY : restB);
-                            int t = 0;
-                            for (; t + 1 < nseg; t += 2) {
-                                curA = opsA.value(max_of(restB, curB), ag_h, alpha_h, gamma_h);      // A: row sA -> row sB
-                                curB = opsB.value(max_of(restA, curA), ag_h, alpha_h, gamma_h);      // B: back
+                    // smallest period p <= 4 of the segment's transition words (lane t against lane t - p)
+                    const uint32_t w1 = dpp_mov32<0x138>(w), w2 = dpp_mov32<0x138>(w1);           // wave_shr:1, twice
+                    const uint32_t w3 = dpp_mov32<0x138>(w2), w4 = dpp_mov32<0x138>(w3);
+                    const bool in_seg = lane < nseg;
+                    const int period = __ballot(in_seg && lane >= 1 && w != w1) == 0ull ? 1
+                                     : __ballot(in_seg && lane >= 2 && w != w2) == 0ull ? 2
+                                     : __ballot(in_seg && lane >= 3 && w != w3) == 0ull ? 3
+                                     : __ballot(in_seg && lane >= 4 && w != w4) == 0ull ? 4 : 0;
+                    if (period > 0 && nseg >= period) {
+                        uint32_t W[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) W[j] = readlane_u(w, j);
+                        // the cycle must close (last -> first) and visit `period` DIFFERENT rows, so that every row
+                        // holds exactly one of the rewritten cells
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (j < period) {
+                                const uint32_t nxt_row = (W[(j + 1 < period) ? j + 1 : 0] >> 16) & 0xFFu;
+                                ok = ok && (W[j] >> 24) == nxt_row;
+#pragma unroll
+                                for (int i = 0; i < j; i++) ok = ok && ((W[i] >> 16) & 0xFFu) != ((W[j] >> 16) & 0xFFu);
                             }
-                            if (t < nseg) curA = opsA.value(max_of(restB, curB), ag_h, alpha_h, gamma_h);
+                        if (ok) {
+                            seg_done = true;
+                            const BlockOps<QT> ops0 = make_ops(snap[seg], 0, r0d, r1d, alpha_h);      // step layout: lane 32h + t
+                            const unsigned tabh = half ? tab1_off : tab0_off;
+                            if (period == 1) cyclic_segment<QT, 1>(ops0, woq.x, W, nseg, lane, tabh, A, row_bytes, ag_h, alpha_h, gamma_h);
+                            else if (period == 2) cyclic_segment<QT, 2>(ops0, woq.x, W, nseg, lane, tabh, A, row_bytes, ag_h, alpha_h, gamma_h);
+                            else if (period == 3) cyclic_segment<QT, 3>(ops0, woq.x, W, nseg, lane, tabh, A, row_bytes, ag_h, alpha_h, gamma_h);
+                            else cyclic_segment<QT, 4>(ops0, woq.x, W, nseg, lane, tabh, A, row_bytes, ag_h, alpha_h, gamma_h);
+                            __builtin_amdgcn_wave_barrier();
                         }
-                        if ((lane & 31) == 0) {
-                            lds_store<QT>(cellA, curA);
-                            if (!fixed1) lds_store<QT>(cellB, curB);
-                        }
-                        __builtin_amdgcn_wave_barrier();
                     }
                 }
                 const bool any_fixed = __ballot((P >> 31) != 0u) != 0ull;
