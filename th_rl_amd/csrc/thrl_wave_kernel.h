@@ -452,7 +452,7 @@ __device__ __forceinline__ void replay_group(int gi, uint32_t P, int lane_base, 
     } while (lo < nv);
 }
 // UNROLL: the block's 8 groups as straight-line code (group numbers become immediates, no loop control):
-// the headline variants; the others keep the loop (code size; hipcc 7.2 also fails on the unrolled noise variants).
+// every variant with <= 128 steps per cycle except float64 + noise (hipcc 7.2 fails on that one: "illegal VGPR to SGPR copy").
 template <typename QT, int RDN, bool FIXED_POINTS, bool UNROLL, bool PER2>
 __device__ __forceinline__ void replay_block(uint32_t P, int lane_base, int nsub, const BlockOps<QT>& ops, unsigned wo,
                                              unsigned rd_base, unsigned row_shift, unsigned my_step,
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(1024)
 __attribute__((amdgpu_waves_per_eu(sizeof(QT) == 8 ? 3 : (NOISE ? 4 : (NSEG <= 2 ? 5 : 4)))))
 k_wave_episodes(const WaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr bool kUnrollReplay = !NOISE && NSEG <= 2;     // the headline shapes (float32 and float64)
+    constexpr bool kUnrollReplay = NSEG <= 2 && !(NOISE && sizeof(QT) == 8);     // (hipcc 7.2 cannot compile the unrolled float64 noise variant)
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // A training cycle = epk episodes played against frozen tables (the replay buffer reaches min_memory
