@@ -381,6 +381,31 @@ def test_wave_greedy_regime_cycles_and_fixed_points_vs_oracle(dtype, eps):
     assert (c.max(axis=1) >= 50).mean() > 0.3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_wave_greedy_variant_equals_generic_kernel_at_16384_games(dtype):
+    """The GREEDY variants of the wave kernel (launched once epsilon <= 0.03: all-greedy groups without a table
+    build, period-2 passes, cyclic segments of period 1-4 as register recurrences) against the generic kernel --
+    independent code, one thread per game, tables in HBM -- on 16,384 games over 40 episodes that start at
+    epsilon 0.02: tables, counters, states and epsilon bit for bit; and the regime really is the cyclic one."""
+    ag = dict(CFG_AGENT, epsilon=0.02, eps_end=0.001)
+    config = {"agents": [dict(ag), dict(ag, alpha=0.3)], "environment": dict(CFG_ENV)}
+    G, E = 16384, 40
+    a = _batch(config, G, dtype=dtype, kernel="wave", seed=5).init_tables()
+    b = _batch(config, G, dtype=dtype, kernel="generic", seed=5).init_tables()
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy())
+    for n in (25, 15):                       # two launches: the second starts on tables the first one trained
+        oa, ob = a.run(n), b.run(n)
+        assert oa["kernel"] == "wave" and ob["kernel"] == "generic"
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy())
+    assert np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy())
+    assert a.eps == b.eps
+    np.testing.assert_allclose(oa["reward_log"], ob["reward_log"], rtol=1e-12)
+    c = a.counters_numpy()
+    assert (c.max(axis=1) >= 400).mean() > 0.05         # a good share of the games rewrite one cell >= 10 times per episode
+
+
 def _cycle_config(T, mm, cap, noise=0.0):
     ag = dict(CFG_AGENT, min_memory=mm, capacity=cap)
     return {"agents": [dict(ag), dict(ag, alpha=0.3, gamma=0.9)], "environment": dict(CFG_ENV, max_steps=T, noise_prob=noise)}
