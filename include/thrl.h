@@ -16,8 +16,10 @@
  * not share mutable state.  The only process-wide state is (i) the thread-local
  * error string, (ii) a read-only cache of per-device figures (CU count, LDS per
  * CU, resident waves per CU from hipDeviceProp_t), keyed by the HIP device id
- * and filled once per device under a lock, and (iii) the tuning knob
- * THRL_WAVE_MAX_WAVES_PER_CU, read from the environment once per process.
+ * and filled once per device under a lock, and (iii) the tuning knobs
+ * THRL_WAVE_MAX_WAVES_PER_CU and THRL_GREEDY_EPS (measurement only: the epsilon
+ * below which the greedy-regime variants of the fused kernel are launched;
+ * results do not depend on it), read from the environment once per process.
  * Launch geometry and thrl_workspace_bytes() refer to the CURRENT HIP device of
  * the calling thread (hipSetDevice / torch.cuda.device).
  *
