@@ -26,7 +26,14 @@
 //     A pass is legal when no transition in it reads a row, or rewrites a cell, that an earlier
 //     transition of the same pass writes; the schedule (where a group of four must be cut into
 //     several passes) is computed lane-parallel before the loop, so results are exactly those of the
-//     serial loop.
+//     serial loop;
+//   * the kernel is bound by the number of instructions a wave issues, so the hot loops are
+//     straight-line code: the play loop is unrolled over a segment's 16 groups of four steps and the replay
+//     loop over a block's 8 groups (step / lane numbers are immediates), with copies for full segments and
+//     full blocks that carry no bounds tests;
+//   * GREEDY variants (launched once epsilon is small): groups of four steps in which nobody explores read
+//     their next rows from per-episode composed tables, and a segment that cycles through 1-4 transitions
+//     (a converged game) is replayed as a recurrence in registers (cyclic_segment).
 #pragma once
 #include <type_traits>
 #include "thrl_kernels.h"
