@@ -401,6 +401,8 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "regions": regions, "region_ms": [t * 1e3 for t in region_s],
+            "region_policy": "each region = exactly `steps` steps between barrier + synchronize (max over ranks); "
+                             "the median region is reported (of an even count the slower middle one)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": "2-agent QTable (21 actions x 101 states, example_config.json) x %d "
