@@ -80,6 +80,17 @@ k_mixed_wave(const MixedArgs a) {
         estep_l = a.sw_eps_step ? a.sw_eps_step[(size_t)lane * a.G + g] : a.ag[lane].eps_step;
     }
     const double noise_prob_g = a.sw_noise_prob ? a.sw_noise_prob[g] : a.env.noise_prob;
+    // Replay-ring state of agent i lives in lane i: its four buffer pointers and its write index (kept
+    // incrementally: count % capacity).  The append is then ONE predicated block of four stores -- no per-agent
+    // loop re-loading pointers from the kernel arguments (that was 8 dependent scalar-load round trips per step).
+    // (Only where registers are free: with a policy network in registers the eight pointer registers spill,
+    // and a spill reload waits for the appends in flight -- measured 10-18 % slower; those variants keep the loop.)
+    constexpr bool kLanePointers = NR == 0;
+    double* my_bp = nullptr; int32_t* my_ba = nullptr; double* my_br = nullptr; double* my_bn = nullptr;
+    if (kLanePointers)
+        for (int i = 0; i < N; i++)
+            if (lane == i) { my_bp = a.buf_price[i]; my_ba = a.buf_action[i]; my_br = a.buf_reward[i]; my_bn = a.buf_nprice[i]; }
+    int widx_l = cap_l > 0 ? cnt_l % cap_l : 0;
     if (NR >= 1) {
         const int A = a.ag[a.ragent[0]].n_actions;
         policy_load(net0, a.nn_params[a.ragent[0]] + (int64_t)g * a.nn_stride[a.ragent[0]], A, lane);
@@ -94,6 +105,10 @@ k_mixed_wave(const MixedArgs a) {
     double price = a.state[g];
     const bool noisy = a.env.noise_prob > 0.0;
     const double Td = (double)Tn;
+    // the environment's constants as register values the optimiser cannot re-load from the kernel arguments inside
+    // the step loop (an s_load + s_waitcnt per use and per step otherwise)
+    double env_a = a.env.a, env_b = a.env.b, env_ratio = a.env.ratio;
+    asm volatile("" : "+s"(env_a), "+s"(env_b), "+s"(env_ratio));
     const int my_agent = lane & 31;
 
     for (int e = 0; e < a.n_episodes; e++) {
@@ -178,33 +193,43 @@ k_mixed_wave(const MixedArgs a) {
                 }
             }
             // ---- NoisyPriceState.step (environments.py:25-39)
-            double a_eff = a.env.a;
+            double a_eff = env_a;
             if (noisy) {
                 const uint32_t nx = lane_u32(xn.x, tl), ny = lane_u32(xn.y, tl);
                 if (u01_32(nx) < noise_prob_g)
-                    a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(ny)));
+                    a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(env_a, a.env.noise_lo), u01_32(ny)));
             }
-            const double A_l = __dmul_rn(a.env.ratio, scaled_l);
+            const double A_l = __dmul_rn(env_ratio, scaled_l);
             double Q = 0.0;
 #pragma unroll
             for (int i = 0; i < NA; i++)
                 if (i < N) Q = __dadd_rn(Q, lane_f64(A_l, i));
-            double next_price = __dsub_rn(a_eff, __dmul_rn(a.env.b, Q));
+            double next_price = __dsub_rn(a_eff, __dmul_rn(env_b, Q));
             if (!(next_price > 0.0)) next_price = 0.0;
             const double rew_l = __dmul_rn(next_price, A_l);
             // ---- memory.append (trainer.py:62), lane i for agent i
+            if (kLanePointers) {
+                if (lane < N && cap_l > 0) {
+                    const size_t m = (size_t)widx_l * G + g;
+                    my_bp[m] = price; my_ba[m] = act_l;
+                    my_br[m] = rew_l; my_bn[m] = next_price;
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < NA; i++) {
-                if (i >= N || a.buf_len[i] <= 0) continue;
-                if (lane == i) {
-                    const size_t m = (size_t)(cnt_l % cap_l) * G + g;
-                    a.buf_price[i][m] = price; a.buf_action[i][m] = act_l;
-                    a.buf_reward[i][m] = rew_l; a.buf_nprice[i][m] = next_price;
+                for (int i = 0; i < NA; i++) {
+                    if (i >= N || a.buf_len[i] <= 0) continue;
+                    if (lane == i) {
+                        const size_t m = (size_t)widx_l * G + g;
+                        a.buf_price[i][m] = price; a.buf_action[i][m] = act_l;
+                        a.buf_reward[i][m] = rew_l; a.buf_nprice[i][m] = next_price;
+                    }
                 }
             }
             if (cap_l > 0) {
                 cnt_l += 1;
                 if (cnt_l >= 2 * cap_l) cnt_l -= cap_l;
+                widx_l += 1;
+                if (widx_l == cap_l) widx_l = 0;
             }
             const double val = lane < N ? rew_l : ((lane >= 32 && lane < 32 + N) ? scaled_l : 0.0);
             acc = __dadd_rn(acc, __ddiv_rn(val, Td));                   // trainer.py:65-66
@@ -258,7 +283,7 @@ k_mixed_wave(const MixedArgs a) {
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
-                if (lane == i) cnt_l = 0;
+                if (lane == i) { cnt_l = 0; widx_l = 0; }
             }
             if (lane == i) eps_l = __dadd_rn(eend_l, __dmul_rn(__dsub_rn(eps_l, eend_l), estep_l));
         }
