@@ -162,6 +162,7 @@ struct MixedArgs {
     int32_t lds_bytes;
     int32_t memo_lds_byte0, memo_on, memo_k;                                   // memoised policy CDFs [n_r][64][APAD] floats
     int32_t n_cac, cac_lds_byte0;                                      // CAC networks (kind 3) live in LDS after the tables
+    int32_t stage_lds_byte0;                                           // 16 steps of transitions staged before they go to the replay rings
     // per-game sweeps of the QTable agents / the env (null = the scalars above), [N][G] except noise_prob [G]
     const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
     double* sw_eps; const double* sw_noise_prob;

@@ -46,6 +46,9 @@ k_mixed_wave(const MixedArgs a) {
     // (noise-free games: one value per pair of actions), so the CDF the policy returns for a state
     // is kept -- kMemo entries per network, tag = the float32 state's bits, lane e of `tag` = entry e.
     float* const lds_memo = reinterpret_cast<float*>(smem_mx + a.memo_lds_byte0);   // [NR][kMemo][APAD]
+    double* const st_price = reinterpret_cast<double*>(smem_mx + a.stage_lds_byte0);       // [16] state before the step
+    double* const st_rew = st_price + 16;                                                   // [16][N]
+    int32_t* const st_act = reinterpret_cast<int32_t*>(st_rew + 16 * a.N);                  // [16][N]
     unsigned tag0 = 0u, tag1 = 0u;
     int nmemo0 = 0, nmemo1 = 0;
     const int g = blockIdx.x, lane = threadIdx.x;
@@ -215,14 +218,32 @@ k_mixed_wave(const MixedArgs a) {
                     my_br[m] = rew_l; my_bn[m] = next_price;
                 }
             } else {
-#pragma unroll
-                for (int i = 0; i < NA; i++) {
-                    if (i >= N || a.buf_len[i] <= 0) continue;
-                    if (lane == i) {
-                        const size_t m = (size_t)widx_l * G + g;
-                        a.buf_price[i][m] = price; a.buf_action[i][m] = act_l;
-                        a.buf_reward[i][m] = rew_l; a.buf_nprice[i][m] = next_price;
+                // Network(s) in registers: the appends are STAGED in LDS and go to the rings 16 steps at a time
+                // (lane = step).  A store in flight makes every spill reload of this register-heavy variant wait
+                // for HBM (loads and stores share vmcnt); staged, the step loop has none in flight.
+                if (lane == 0) st_price[tl] = price;
+                if (lane < N && cap_l > 0) { st_rew[tl * N + lane] = rew_l; st_act[tl * N + lane] = act_l; }
+                if (tl == 15 || t == Tn - 1) {
+                    const int nb = tl + 1;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < N; i++) {
+                        const int cap = a.buf_len[i];
+                        if (cap <= 0) continue;
+                        int w0 = __builtin_amdgcn_readlane(widx_l, i) - tl;        // ring slot of the batch's first step
+                        while (w0 < 0) w0 += cap;
+                        // (a ring shorter than the batch: only the last `cap` steps survive, as with one store per step)
+                        if (lane < nb && lane >= nb - cap) {
+                            int slot = w0 + lane;
+                            while (slot >= cap) slot -= cap;
+                            const size_t m = (size_t)slot * G + g;
+                            a.buf_price[i][m] = st_price[lane];
+                            a.buf_action[i][m] = st_act[lane * N + i];
+                            a.buf_reward[i][m] = st_rew[lane * N + i];
+                            a.buf_nprice[i][m] = lane + 1 < nb ? st_price[lane + 1] : next_price;
+                        }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             if (cap_l > 0) {
@@ -367,6 +388,10 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
     // network, 8 with two).  A grid that does not fit was measured: QTable vs Reinforce has 441
     // prices, a 40-entry memo hits ~35 % of the steps early in training and the lookups cost more
     // than that saves (9.8 vs 9.2 ms per episode of 65,536 games), so it stays off there.
+    // staging of 16 steps of appends: price [16] f64, then per step and agent reward f64 [16][N], action i32 [16][N]
+    a.stage_lds_byte0 = a.lds_bytes;
+    a.lds_bytes += 16 * 8 + 16 * a.N * 12;
+    a.lds_bytes = (a.lds_bytes + 15) & ~15;
     a.memo_lds_byte0 = a.lds_bytes;
     a.memo_on = 0; a.memo_k = 0;
     if (a.n_r > 0 && a.n_cac == 0 && a.env.noise_prob <= 0.1) {
