@@ -108,6 +108,28 @@ __device__ __forceinline__ float wave_sum32_transposed(float (&v)[32], int lane)
     return v[0] + dpp_f<kQuadXor1>(v[0]);
 }
 
+// the levels of wave_sum32_transposed below its first one (16 slots, already folded over lane bit 5)
+__device__ __forceinline__ float wave_sum16_transposed(float (&v)[16], int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { swap16(v[i], v[i + 8]); v[i] = v[i] + v[i + 8]; }          // slot bit3 = lane bit4
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                                                            // slot bit2 = lane bit3
+        const float keep = b3 ? v[i + 4] : v[i], give = b3 ? v[i] : v[i + 4];
+        v[i] = keep + dpp_f<kRowMirror>(give);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                                                            // slot bit1 = lane bit2
+        const float keep = b2 ? v[i + 2] : v[i], give = b2 ? v[i] : v[i + 2];
+        v[i] = keep + dpp_f<kRowHalfMirror>(give);
+    }
+    {                                                                                        // slot bit0 = lane bit1
+        const float keep = b1 ? v[1] : v[0], give = b1 ? v[0] : v[1];
+        v[0] = keep + dpp_f<kQuadXor2>(give);
+    }
+    return v[0] + dpp_f<kQuadXor1>(v[0]);
+}
+
 typedef float pf2 __attribute__((ext_vector_type(2)));
 
 template <int APAD>
@@ -138,17 +160,27 @@ __device__ __forceinline__ float policy_probs(const PolicyRegs<APAD>& r, int A, 
     float h[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) h[j] = fmaxf(__fmaf_rn(r.w1[j], x, r.b1[j]), 0.0f);
-    float v[32];
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
+    // The 32 per-lane logit slots are produced pair by pair and folded at once with their partner 16 slots up
+    // (the first level of wave_sum32_transposed: the same swaps and additions in the same order, so the same
+    // bits) -- 16 live accumulators instead of 32: with two networks in registers those 16 decide between
+    // fitting the register file and spilling in the step loop.
+    float v[16];
+    auto dot = [&](int p) {
         pf2 s = pf2{0.0f, 0.0f};
         if (2 * p < APAD) {
 #pragma unroll
             for (int j = 0; j < 4; j++) s = __builtin_elementwise_fma(r.w2[p][j], pf2{h[j], h[j]}, s);
         }
-        v[2 * p] = s.x; v[2 * p + 1] = s.y;
+        return s;
+    };
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const pf2 lo = dot(p), hi = dot(p + 8);
+        float a0 = lo.x, b0 = hi.x, a1 = lo.y, b1 = hi.y;
+        swap32(a0, b0); swap32(a1, b1);                                                      // slot bit4 = lane bit5
+        v[2 * p] = a0 + b0; v[2 * p + 1] = a1 + b1;
     }
-    const float z = wave_sum32_transposed(v, lane) + r.b2;
+    const float z = wave_sum16_transposed(v, lane) + r.b2;
     const int k = lane >> 1;
     const bool valid = k < A, mine = valid && !(lane & 1);
     const float m = wave_all(valid ? z : -INFINITY, OpMax());
