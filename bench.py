@@ -11,7 +11,7 @@ float32 tables, int32 visit counters, Philox draws, synthetic random-init tables
 One "step" = one episode (T=100 env-steps, both agents acting and learning) of every
 game.  A kernel launch covers --chunk episodes (tables stay in LDS inside a launch; 32 at most);
 by default the K steps of a timed region are ONE launch when K <= 32 (what a training loop does:
-trainer.train_one launches 25-32 episodes at a time), otherwise equal launches of <= 32.  The
+thrl_qtable_episodes cuts a training call into launches of 32 episodes), otherwise equal launches of <= 32.  The
 timed region -- exactly K steps between barrier + synchronize on both sides, max over ranks -- is
 repeated until >= 4 launches have been timed (K = 20: four regions) and the MEDIAN region is
 reported; every region's time is in the line (`region_ms`), the per-launch HIP-event average of
