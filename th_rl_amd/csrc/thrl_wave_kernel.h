@@ -876,7 +876,12 @@ k_wave_episodes(const WaveArgs a) {
                 THRL_PLAY2(8, N_) THRL_PLAY2(10, N_) THRL_PLAY2(12, N_) THRL_PLAY2(14, N_)
                 // the same with the all-greedy groups skipping their table build (g0: the group the chain runs next)
 #define THRL_PLAY2G(G, N_)                                                                   \
-                if ((G) * 4 < (N_)) {                                                        \
+                if ((G) * 4 + 8 <= (N_) && g0 &&                                             \
+                    !(busy_groups & (((G) * 4 + 8 < 64 ? 0x110ull : 0x10ull) << ((G) * 4)))) {   \
+                    /* this group, the next one and the one after it are all-greedy: two chains, no build, one test */ \
+                    chain4(std::integral_constant<int, (G) * 4>(), (N_), ta, true);          \
+                    chain4(std::integral_constant<int, (G) * 4 + 4>(), (N_), tb, true);      \
+                } else if ((G) * 4 < (N_)) {                                                 \
                     const bool g1 = !((busy_groups >> ((G) * 4 + 4)) & 1ull);                \
                     if ((G) * 4 + 4 < (N_) && !g1) build4((G) * 4 + 4, tb);                  \
                     chain4(std::integral_constant<int, (G) * 4>(), (N_), ta, g0);            \
