@@ -713,6 +713,7 @@ k_wave_episodes(const WaveArgs a) {
             // ---- (b,c) play: lane-parallel Philox, then the serial state chain.
             //      seq[seg] lane t = row in which step t was played.
             uint32_t seq[NSEG], rwv[NSEG];
+            unsigned explored_segs = 0u;   // GREEDY: bit seg = somebody explored in that segment (it cannot be one cycle then)
             double nav[NSEG];              // NOISE: the uniform(0.7a, a) draw of a noisy step (lane = step)
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
@@ -782,6 +783,7 @@ k_wave_episodes(const WaveArgs a) {
                 // noisy, or it lies beyond the segment's end)
                 unsigned long long busy_groups = 0ull;
                 if (GREEDY && NRSEG == 1) {
+                    if (__ballot((rw & 3u) != 0u && seg * 64 + lane < T) != 0ull) explored_segs |= 1u << seg;
                     busy_groups = __ballot((rw & (NOISE ? 7u : 3u)) != 0u || seg * 64 + lane >= T);
                     busy_groups |= busy_groups >> 1;
                     busy_groups |= busy_groups >> 2;
@@ -1031,7 +1033,7 @@ k_wave_episodes(const WaveArgs a) {
                 // per cycle position and agent: the rows are read once, split into "the cell" and "the max of the rest",
                 // and the segment's transitions run in registers -- two vector instructions each (cyclic_segment).
                 bool seg_done = false;
-                if (GREEDY && !(kAblate & 257)) {
+                if (GREEDY && !(kAblate & 257) && !((explored_segs >> seg) & 1u)) {
                     const int nseg = min(64, T - seg * 64);
                     const uint32_t w = act[seg];
                     // smallest period p <= 4 of the segment's transition words (lane t against lane t - p)
