@@ -232,6 +232,50 @@ def bench_nn(args):
     print(json.dumps(out))
 
 
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising the HIP runtime (the launcher must not: its children
+    are the ranks).  torch.cuda.device_count() only enumerates on this image."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def self_launch(n, argv, allow_oversubscribe=False, popen=None):
+    """`python bench.py --gpus N` without a torch.distributed launcher: spawn N child ranks of this script (one
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set),
+    relay rank 0's JSON line, return the worst exit code.  The parent never touches the GPU and reports
+    nothing of its own -- a line with n_gpus = N only ever comes from N ranks that ran.  Refuses (exit 2) when
+    the box shows fewer than N GPUs, unless --allow-oversubscribe (rehearsal: ranks share devices modulo the
+    count and the line says so)."""
+    import socket
+    import subprocess
+    have = visible_gpus()
+    if have < n and not allow_oversubscribe:
+        print("bench.py: --gpus %d but only %d GPU(s) visible: refusing to report an %d-GPU number "
+              "(--allow-oversubscribe shares devices for a rehearsal)" % (n, have, n), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    popen = popen or subprocess.Popen
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print("bench.py: child ranks exited with %s" % rcs, file=sys.stderr)
+        return max(abs(rc) for rc in rcs) or 1
+    sys.stdout.write(out0.decode() if isinstance(out0, bytes) else (out0 or ""))
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,6 +296,9 @@ def main():
     ap.add_argument("--workload", default="qtable", choices=["qtable", "nn"],
                     help="qtable = the headline metric (default); nn = BASELINE configs[3]: 2 Reinforce "
                          "agents x 65,536 games through the fused episode + update kernels (secondary)")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="rehearsal only: let --gpus N run on fewer than N GPUs (ranks share devices; the line is "
+                         "flagged `oversubscribed`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
@@ -271,14 +318,21 @@ def main():
                          "(the reference's config trains 20,000 episodes; epsilon is 0.004 after 10,000)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- N child ranks, nothing touches the GPU here
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.allow_oversubscribe))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        n_gpus = world
+    # the GPU count of the line is the number of ranks that RUN, never the flag
+    n_gpus = world
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting n_gpus=%d" % (args.gpus, world, world), file=sys.stderr)
 
     if args.workload == "nn":
+        if world > 1:
+            print("bench.py: --workload nn is a single-GPU line", file=sys.stderr)
+            sys.exit(2)
         return bench_nn(args)
 
     cpu = None
@@ -293,7 +347,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     # one rank per GPU; the modulo only matters when rehearsing N ranks on a box with fewer GPUs
-    dev = torch.device("cuda", (local_rank % max(1, torch.cuda.device_count())) if world > 1 else 0)
+    n_dev = max(1, torch.cuda.device_count())
+    if world > n_dev and not args.allow_oversubscribe:
+        print("bench.py: %d ranks but %d GPU(s) visible (--allow-oversubscribe for a rehearsal)" % (world, n_dev), file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", (local_rank % n_dev) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     G = args.games
@@ -410,7 +468,8 @@ def main():
                                    % (G, T_run),
                        "games_per_gpu": G, "episodes_per_launch": e_launch, "kernel": gb.last_kernel,
                        "counters": not args.no_counters, "epsilon_start": eps_at_start, "pretrain_episodes": args.pretrain,
-                       "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus},
+                       "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus,
+                       "devices_visible": n_dev, "oversubscribed": world > n_dev},
             "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -19,7 +19,8 @@
  * and filled once per device under a lock, and (iii) the tuning knobs
  * THRL_WAVE_MAX_WAVES_PER_CU and THRL_GREEDY_EPS (measurement only: the epsilon
  * below which the greedy-regime variants of the fused kernel are launched;
- * results do not depend on it), read from the environment once per process.
+ * results do not depend on it), read from the environment once per process
+ * (per call: thrl_run.kernel = THRL_KERNEL_WAVE_PLAIN / THRL_KERNEL_WAVE_GREEDY).
  * Launch geometry and thrl_workspace_bytes() refer to the CURRENT HIP device of
  * the calling thread (hipSetDevice / torch.cuda.device).
  *
@@ -35,7 +36,8 @@
 extern "C" {
 #endif
 
-#define THRL_ABI_VERSION 2          /* 2: per-game sweeps in thrl_qtable_init, thrl_mixed and the *_train entry points */
+#define THRL_ABI_VERSION 3          /* 2: per-game sweeps in thrl_qtable_init, thrl_mixed and the *_train entry points;
+                                       3: thrl_build_info, THRL_KERNEL_WAVE_PLAIN / _GREEDY, replay rings [G][buf_len] */
 #define THRL_MAXA 8          /* max agents per game (reference configs use 2) */
 #define THRL_MAX_EPISODES_PER_LAUNCH 32
 
@@ -51,7 +53,14 @@ typedef enum {
 typedef enum {
     THRL_KERNEL_AUTO = 0,       /* fused wave kernel when eligible, else generic */
     THRL_KERNEL_GENERIC = 1,    /* one thread per game, tables in HBM, f32/f64  */
-    THRL_KERNEL_WAVE = 2        /* one wavefront per game, tables in LDS, f32   */
+    THRL_KERNEL_WAVE = 2,       /* one wavefront per game, tables in LDS, f32 / f64 */
+    /* The wave kernel has two code variants with IDENTICAL results: the plain one and the greedy-regime one
+     * (per-episode composed greedy tables, cyclic segments as register recurrences); THRL_KERNEL_WAVE picks by
+     * epsilon (the greedy one once every agent's epsilon <= 0.035).  These two ids pin the variant for one call
+     * -- measurements and the parity tests that cover each variant in each regime.  _GREEDY fails with
+     * THRL_ERR_UNSUPPORTED where no greedy variant exists (noise, sweeps, multi-episode training cycles). */
+    THRL_KERNEL_WAVE_PLAIN = 3,
+    THRL_KERNEL_WAVE_GREEDY = 4
 } thrl_kernel;
 
 /*
@@ -133,6 +142,12 @@ typedef struct {
 
 int         thrl_version(void);
 const char* thrl_last_error(void);
+/* What this binary is: "abi=3;ablate=<mask>;src=<hash of the sources it was built from>".  ablate != 0 marks a
+ * TIMING-ONLY diagnostic build (phases of the fused kernel compiled out, results wrong by construction;
+ * profiles/ablate.py) -- callers that report results or throughput must refuse it (bench.py does). */
+const char* thrl_build_info(void);
+/* the ablation mask alone (0 = the product library) */
+int         thrl_ablate_mask(void);
 
 /* elements per game in q / counter (sum_i rows_i*A_i); 0 on bad config */
 size_t thrl_table_stride(const thrl_cfg* cfg);

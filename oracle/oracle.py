@@ -12,7 +12,11 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libthrl_oracle.so")
+# THRL_ORACLE_SANITIZE=1: load the ASan + UBSan build instead (the process must have libasan preloaded;
+# tests/test_host_cpu.py::test_oracle_golden_under_sanitizers does that in a child process)
+SANITIZE = os.environ.get("THRL_ORACLE_SANITIZE") == "1"
+LIB_NAME = "libthrl_oracle_san.so" if SANITIZE else "libthrl_oracle.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
 MAXA = 8
 
 
@@ -70,7 +74,7 @@ def build(force=False):
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", HERE, "-B", "libthrl_oracle.so"])
+    subprocess.check_call(["make", "-s", "-C", HERE, "-B", LIB_NAME])
     return LIB_PATH
 
 

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared and set(declared) == set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.thrl_version() == 2
+    assert lib.thrl_version() == 3
 
 
 def test_struct_layout_matches_header(lib):
@@ -345,3 +345,101 @@ def test_load_experiment_reads_the_run_the_reference_ships():
     assert np.array_equal(agents[1].flat_params()[:256], sd["fc1.weight"].numpy().ravel())
     assert list(actions.columns) == ["QTable0", "Reinforce1"] and actions.shape == rewards.shape == (201, 2)
     assert config["training"]["epochs"] == 20000
+
+
+def test_build_info_names_the_binary(lib):
+    """thrl_build_info(): ABI version, ablation mask (0 = the product library) and the hash of the sources the
+    binary was built from -- bench.py prints it and refuses an ablation build for any reported number."""
+    from th_rl_amd import _lib, build
+    info = _lib.build_info()
+    assert info["abi"] == 3 and info["ablate"] == 0 and lib.thrl_ablate_mask() == 0
+    assert info["src"] == build.source_hash() and re.fullmatch(r"[0-9a-f]{12}", info["src"])
+    assert info["path"].endswith("libthrl_hip.so")
+
+
+def test_kernel_variant_ids_are_validated_on_the_host(lib):
+    """thrl_run.kernel accepts the two variant-pinning ids; an unknown id is THRL_ERR_BAD_CONFIG (no GPU needed:
+    validation happens before any launch)."""
+    from th_rl_amd import _lib
+    cfg, eps = _lib.cfg_from_config(CFG, 8, 0)
+    b, r = _lib.Buffers(), _lib.Run()
+    b.q = b.state = 1          # non-NULL; never dereferenced on this path
+    r.n_episodes, r.kernel = 1, 7
+    assert lib.thrl_qtable_episodes(ctypes.byref(cfg), ctypes.byref(b), ctypes.byref(r), None) == -1
+    assert b"unknown kernel id 7" in lib.thrl_last_error()
+    assert (_lib.KERNEL_WAVE_PLAIN, _lib.KERNEL_WAVE_GREEDY) == (3, 4)
+    header = open(os.path.join(ROOT, "include", "thrl.h")).read()
+    assert "THRL_KERNEL_WAVE_PLAIN = 3" in header and "THRL_KERNEL_WAVE_GREEDY = 4" in header
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_n_spawns_n_ranks_or_refuses(monkeypatch, capsys):
+    """`python bench.py --gpus N` as a plain command (no WORLD_SIZE): the parent becomes a launcher that starts N
+    child ranks with RANK / WORLD_SIZE / MASTER_* set and relays rank 0's line -- or refuses when fewer than N GPUs are
+    visible.  It never prints an N-GPU line from one process (round-2 verdict / advisor finding)."""
+    bench = _load_bench()
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            started.append((cmd, env))
+            self.rank = int(env["RANK"])
+        def communicate(self):
+            return (b'{"n_gpus": 2}\n', None)
+        def wait(self):
+            return 0
+
+    # no GPU visible here: refuses, starts nothing
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 0)
+    assert bench.self_launch(2, ["--gpus", "2"], popen=FakeProc) == 2 and not started
+    assert "refusing" in capsys.readouterr().err
+    # enough GPUs: N children, each with its rank and the same rendezvous
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    assert bench.self_launch(4, ["--gpus", "4", "--steps", "3"], popen=FakeProc) == 0
+    assert len(started) == 4
+    assert [e["RANK"] for _, e in started] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" for _, e in started)
+    assert len({e["MASTER_PORT"] for _, e in started}) == 1
+    assert all(c[1].endswith("bench.py") and c[2:] == ["--gpus", "4", "--steps", "3"] for c, _ in started)
+    assert capsys.readouterr().out.strip() == '{"n_gpus": 2}'
+    # a failing child fails the launch and nothing is relayed
+    FakeProc.wait = lambda self: 3 if self.rank == 1 else 0
+    assert bench.self_launch(2, ["--gpus", "2"], popen=FakeProc) == 3
+    assert capsys.readouterr().out == ""
+
+
+def test_bench_gpus_2_as_a_plain_command_fails_loudly_without_gpus():
+    """End to end, in a real child process: no WORLD_SIZE, --gpus 2, no GPU in this container => exit code 2 and no
+    JSON line (before the fix: one process printed n_gpus 2 and twice the single-GPU value)."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == "" and "refusing" in p.stderr
+
+
+def test_oracle_golden_under_sanitizers():
+    """AddressSanitizer + UndefinedBehaviorSanitizer build of oracle/thrl_oracle.c (oracle/Makefile,
+    libthrl_oracle_san.so) run under the whole golden suite in a child process with libasan preloaded: the
+    sanitizers' home on this pool is the CPU build."""
+    import subprocess, sys
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("gcc has no libasan here")
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", THRL_ORACLE_SANITIZE="1")
+    code = ("import sys, pytest; from oracle import oracle as O; "
+            "assert O.LIB_PATH.endswith('libthrl_oracle_san.so'); "
+            "rc = pytest.main(['-x', '-q', '-p', 'no:cacheprovider', 'tests/test_oracle_golden.py']); "
+            "assert 'libthrl_oracle_san.so' in open('/proc/self/maps').read(); sys.exit(int(rc))")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr

@@ -8,8 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THRL_LIB") or os.path.join(HERE, "libthrl_hip.so")
 MAXA = 8
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE_PLAIN, KERNEL_WAVE_GREEDY = 0, 1, 2, 3, 4
 KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wave"}
+ABI_VERSION = 3
 
 
 class ThrlError(RuntimeError):
@@ -76,7 +77,7 @@ class Mixed(ctypes.Structure):
 
 # every symbol include/thrl.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "thrl_version", "thrl_last_error", "thrl_table_stride", "thrl_table_offset",
+    "thrl_version", "thrl_last_error", "thrl_build_info", "thrl_ablate_mask", "thrl_table_stride", "thrl_table_offset",
     "thrl_replay_mem_bytes", "thrl_workspace_bytes", "thrl_select_kernel", "thrl_training_cycle", "thrl_qtable_init",
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
@@ -121,6 +122,8 @@ def load():
     cfgp = ctypes.POINTER(Cfg)
     L.thrl_version.restype = ctypes.c_int
     L.thrl_last_error.restype = ctypes.c_char_p
+    L.thrl_build_info.restype = ctypes.c_char_p
+    L.thrl_ablate_mask.restype = ctypes.c_int
     for n in ("thrl_table_stride", "thrl_replay_mem_bytes", "thrl_workspace_bytes"):
         getattr(L, n).restype = ctypes.c_size_t
         getattr(L, n).argtypes = [cfgp]
@@ -175,10 +178,17 @@ def load():
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
     L.thrl_mixed_episodes.restype = ctypes.c_int
     L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
-    if L.thrl_version() != 2:
+    if L.thrl_version() != ABI_VERSION:
         raise ThrlError("th_rl_amd: ABI version mismatch (%d)" % L.thrl_version())
     _lib = L
     return L
+
+
+def build_info():
+    """dict(path, abi, ablate, src) of the loaded library (thrl_build_info)."""
+    L = load()
+    d = dict(kv.split("=", 1) for kv in L.thrl_build_info().decode().split(";"))
+    return dict(path=LIB_PATH, abi=int(d["abi"]), ablate=int(d["ablate"]), src=d["src"])
 
 
 def check(rc, what):

@@ -15,7 +15,10 @@ import numpy as np
 from . import _lib
 from ._lib import ThrlError
 
-_KERNELS = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "wave": _lib.KERNEL_WAVE}
+_KERNELS = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "wave": _lib.KERNEL_WAVE,
+            # the wave kernel with its code variant pinned (same results; include/thrl.h)
+            "wave_plain": _lib.KERNEL_WAVE_PLAIN, "wave_greedy": _lib.KERNEL_WAVE_GREEDY}
+_WAVE_IDS = (_lib.KERNEL_WAVE, _lib.KERNEL_WAVE_PLAIN, _lib.KERNEL_WAVE_GREEDY)
 
 
 def _torch():
@@ -189,7 +192,7 @@ class GameBatch:
                             or (bool(self.sweep) and not all(self.cfg.min_memory[i] <= T <= self.cfg.capacity[i]
                                                                  for i in range(N)))
                             or any(self.mem_count[i] for i in range(N)))
-            if will_generic and self.kernel != _lib.KERNEL_WAVE:
+            if will_generic and self.kernel not in _WAVE_IDS:
                 self._ensure_replay_mem()
             if self.replay_mem is not None:
                 b.replay_mem, b.replay_mem_bytes = self._ptr(self.replay_mem), self.replay_mem.numel()

@@ -39,6 +39,17 @@ def up_to_date(lib=LIB):
     return all(os.path.getmtime(d) <= t for d in _deps())
 
 
+def source_hash():
+    """sha1 (12 hex digits) over the kernel sources, headers and compiler flags: what thrl_build_info() reports
+    as `src=` and profiles/traffic.json records, so bench.py can tell when its PMC constants were collected on
+    another kernel."""
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=False, ablate=0, out=None):
     """Each source is compiled to an object in parallel (one hipcc per source), then linked."""
     lib = os.path.abspath(out) if out else LIB
@@ -52,10 +63,14 @@ def build(force=False, verbose=False, ablate=0, out=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 
+    src_hash = source_hash()
+
     def compile_one(src):
         flags = list(cflags)
         if ablate and src == "thrl_wave_f32.hip":
             flags.append("-DTHRL_ABLATE=%d" % ablate)
+        if src == "thrl_api.hip":           # thrl_build_info(): which binary is this
+            flags += ["-DTHRL_BUILD_ABLATE=%d" % ablate, '-DTHRL_SRC_HASH="%s"' % src_hash]
         key = hashlib.sha1((" ".join(flags) + hipcc).encode()).hexdigest()[:10]
         obj = os.path.join(OBJ_DIR, "%s-%s.o" % (src.replace(".hip", ""), key))
         path = os.path.join(CSRC, src)

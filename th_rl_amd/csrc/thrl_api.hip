@@ -282,6 +282,20 @@ extern "C" {
 int thrl_version(void) { return THRL_ABI_VERSION; }
 const char* thrl_last_error(void) { return g_err; }
 
+// th_rl_amd/build.py passes the ablation mask of the build and a hash of the sources
+#ifndef THRL_BUILD_ABLATE
+#define THRL_BUILD_ABLATE 0
+#endif
+#ifndef THRL_SRC_HASH
+#define THRL_SRC_HASH "unknown"
+#endif
+#define THRL_STR2(x) #x
+#define THRL_STR(x) THRL_STR2(x)
+const char* thrl_build_info(void) {
+    return "abi=" THRL_STR(THRL_ABI_VERSION) ";ablate=" THRL_STR(THRL_BUILD_ABLATE) ";src=" THRL_SRC_HASH;
+}
+int thrl_ablate_mask(void) { return THRL_BUILD_ABLATE; }
+
 size_t thrl_table_stride(const thrl_cfg* c) {
     if (!c || c->n_agents < 1 || c->n_agents > THRL_MAXA) return 0;
     size_t s = 0;
@@ -398,7 +412,7 @@ static int run_generic(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, 
     return THRL_OK;
 }
 
-static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, const WavePlan& p, hipStream_t s) {
+static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, const WavePlan& p, int force_variant, hipStream_t s) {
     if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
     if (b->inj_u && c->noise_prob > 0.0 && (!b->inj_noise_u || !b->inj_noise_a))
         return fail(THRL_ERR_NULL, "noise_prob > 0 with injected draws needs inj_noise_u/inj_noise_a");
@@ -412,6 +426,7 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     a.row_lo = p.row_lo; a.win_rows = p.win_rows;
     a.epk = p.epk; a.replay_from = p.replay_from;
     a.waves_per_block = p.waves_per_block;
+    a.force_variant = force_variant;
     a.lut_bytes = p.lut_bytes; a.game_lds_bytes = p.game_lds_bytes;
     a.stride = (int64_t)thrl_table_stride(c);
     AgentParams ag[THRL_MAXA];
@@ -444,6 +459,10 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     if (b->sweep_noise_prob && !(c->noise_prob > 0.0))
         return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it sizes the row window)");
     const int chunk_max = kWaveMaxEpisodes / p.epk * p.epk;        // whole training cycles per launch
+    if (force_variant == 2 && (p.epk > 1 || p.replay_from > 0 || c->noise_prob > 0.0 || b->sweep_gamma || b->sweep_alpha ||
+                               b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob))
+        return fail(THRL_ERR_UNSUPPORTED, "THRL_KERNEL_WAVE_GREEDY: no greedy-regime variant for noise, sweeps or "
+                                          "multi-episode training cycles");
 
     const int block = p.waves_per_block * 64;
     const int grid = ws.grid;                             // persistent grid; games are handed out by a work counter
@@ -497,15 +516,18 @@ int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run
     const bool injected = b->inj_u != nullptr;
     const bool per_game_logs = b->game_reward_log || b->game_action_log;
     int k = run->kernel;
-    if (k != THRL_KERNEL_AUTO && k != THRL_KERNEL_GENERIC && k != THRL_KERNEL_WAVE)
+    if (k != THRL_KERNEL_AUTO && k != THRL_KERNEL_GENERIC && k != THRL_KERNEL_WAVE && k != THRL_KERNEL_WAVE_PLAIN &&
+        k != THRL_KERNEL_WAVE_GREEDY)
         return fail(THRL_ERR_BAD_CONFIG, "unknown kernel id %d", k);
+    const int force_variant = k == THRL_KERNEL_WAVE_PLAIN ? 1 : (k == THRL_KERNEL_WAVE_GREEDY ? 2 : 0);
+    if (force_variant) k = THRL_KERNEL_WAVE;
     if (k != THRL_KERNEL_GENERIC) {
         WavePlan p = plan_wave(c, run, injected);
         if (p.ok && per_game_logs) { p.ok = false; snprintf(p.why, sizeof(p.why), "per-game logs requested"); }
         if (p.ok && (p.epk > 1 || p.replay_from > 0) && (b->sweep_gamma || b->sweep_alpha || b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob)) {
             p.ok = false; snprintf(p.why, sizeof(p.why), "per-game sweeps with a multi-episode training cycle or a truncated deque");
         }
-        if (p.ok) return run_wave(c, b, run, p, (hipStream_t)stream);
+        if (p.ok) return run_wave(c, b, run, p, force_variant, (hipStream_t)stream);
         if (k == THRL_KERNEL_WAVE) return fail(THRL_ERR_UNSUPPORTED, "wave kernel cannot run this config: %s", p.why);
     }
     return run_generic(c, b, run, (hipStream_t)stream);

@@ -53,6 +53,7 @@ struct WaveArgs {
     int32_t n_episodes;
     int32_t waves_per_block;
     int32_t total_waves;
+    int32_t force_variant;          // 0: plain / GREEDY by epsilon; 1: plain; 2: GREEDY (thrl_kernel WAVE_PLAIN / WAVE_GREEDY)
     int32_t lut_bytes;              // LDS bytes of the payoff LUT region
     int32_t game_lds_bytes;         // LDS bytes per wave (tables)
     int64_t stride;

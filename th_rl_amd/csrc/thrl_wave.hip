@@ -77,7 +77,10 @@ int launch_wave(const WaveArgs& a, int q_dtype, int grid, int block, size_t lds,
     // tables (262,144 games), plain vs GREEDY: 3.12 vs 2.95e10 at epsilon 0.068, 3.07 vs 3.04 at 0.042, 2.98 vs 3.14 at
     // 0.026, 2.89 vs 3.33 at 0.010 -- its per-group tests cost up to 6 % while the agents still explore.  Same results
     // either way.
-    const bool greedy = !cycle && variant == 0 && a.eps[0][0] <= greedy_eps() && a.eps[0][1] <= greedy_eps();
+    const bool greedy_exists = !cycle && variant == 0;
+    if (a.force_variant == 2 && !greedy_exists) return -2;               // (thrl_api.hip turns it into THRL_ERR_UNSUPPORTED)
+    const bool greedy = greedy_exists && a.force_variant != 1 &&
+                        (a.force_variant == 2 || (a.eps[0][0] <= greedy_eps() && a.eps[0][1] <= greedy_eps()));
     if (q_dtype == 1) {
         switch (variant) {
             case 0: return cycle ? launch_wave_f64_plain_cycle(a, grid, block, lds, s)

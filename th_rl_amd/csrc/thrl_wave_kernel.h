@@ -782,8 +782,8 @@ k_wave_episodes(const WaveArgs a) {
                 // bit 4g: group g (steps 4g..4g+3) has a step that needs its own table (somebody explores, the step is
                 // noisy, or it lies beyond the segment's end)
                 unsigned long long busy_groups = 0ull;
+                if (GREEDY && __ballot((rw & 3u) != 0u && seg * 64 + lane < T) != 0ull) explored_segs |= 1u << seg;
                 if (GREEDY && NRSEG == 1) {
-                    if (__ballot((rw & 3u) != 0u && seg * 64 + lane < T) != 0ull) explored_segs |= 1u << seg;
                     busy_groups = __ballot((rw & (NOISE ? 7u : 3u)) != 0u || seg * 64 + lane >= T);
                     busy_groups |= busy_groups >> 1;
                     busy_groups |= busy_groups >> 2;
@@ -1020,7 +1020,11 @@ k_wave_episodes(const WaveArgs a) {
                     // bit 31: the group runs in registers (replay_group): four identical transitions that stay in
                     // their row, or a period-2 cycle A, B, A, B between two different rows (told apart by rows 0 / 1)
                     // (the period-2 path only in the GREEDY variants: while the agents explore there are no such groups)
-                    const uint32_t same4 = ((b0 == b1 && b1 == b2 && b2 == b3 && (b0 >> 24) == ((b0 >> 16) & 0xFFu)) ||
+                    // NOISE: a noisy step that stays in its row has the SAME word as its neighbours but another reward
+                    // (environments.py:29-33: the intercept is drawn), so its group must take the ordinary passes
+                    bool quad_quiet = true;
+                    if (NOISE) quad_quiet = ((__ballot((rwv[seg] & 4u) != 0u) >> (lane & 60)) & 0xFull) == 0ull;
+                    const uint32_t same4 = ((quad_quiet && b0 == b1 && b1 == b2 && b2 == b3 && (b0 >> 24) == ((b0 >> 16) & 0xFFu)) ||
                                             (GREEDY && b0 == b2 && b1 == b3 && (b0 >> 24) == ((b1 >> 16) & 0xFFu) &&
                                              (b1 >> 24) == ((b0 >> 16) & 0xFFu) && (b0 >> 24) != (b1 >> 24))) ? 1u : 0u;
                     P = (b0 >> 24) | ((b1 >> 24) << 7) | ((b2 >> 24) << 14) | ((b3 >> 24) << 21) |
