@@ -142,7 +142,8 @@ typedef struct {
 
 int         thrl_version(void);
 const char* thrl_last_error(void);
-/* What this binary is: "abi=3;ablate=<mask>;src=<hash of the sources it was built from>".  ablate != 0 marks a
+/* What this binary is: "abi=3;ablate=<mask>;src=<hash of all kernel sources>;wave=<hash of the sources of the
+ * headline kernel>;nn=<hash of the neural-agent kernels' sources>".  ablate != 0 marks a
  * TIMING-ONLY diagnostic build (phases of the fused kernel compiled out, results wrong by construction;
  * profiles/ablate.py) -- callers that report results or throughput must refuse it (bench.py does). */
 const char* thrl_build_info(void);
@@ -232,8 +233,10 @@ int thrl_op_td_update(const thrl_cfg* cfg, int agent, void* q, int32_t* counter,
  * Neural policy agent `Reinforce` (agents.py:119-220): a 1 -> 256 -> A MLP per game.
  * Parameter vector per game, P = thrl_nn_param_count(A) floats:
  *   [fc1.weight (256) | fc1.bias (256) | fc_pi.weight (A x 256 row-major) | fc_pi.bias (A)]
- * All arrays are device pointers, game-major ([G][P]) for parameters and Adam moments,
- * transition-major ([n][G]) for the replayed buffer.  float32 arithmetic as in torch.
+ * All arrays are device pointers and game-major: [G][P] for parameters and Adam moments, [G][ld] for the replayed
+ * buffer (row g = game g's transitions in insertion order, the first n of its ld entries; ABI v3 -- v2 was
+ * transition-major [n][G], which put one game's batch 8*G bytes apart: one 64-byte sector per transition).
+ * float32 arithmetic as in torch.
  */
 #define THRL_NN_HIDDEN 256
 #define THRL_NN_MAX_TRANSITIONS 1400
@@ -251,10 +254,11 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
 /* Reinforce.train_net's update (agents.py:171-193) for G games on n replayed transitions each:
  * discounted returns, z-score (unbiased std), policy-gradient + entropy loss, gradient-norm clip
  * at 1.0, one Adam step (lr, betas 0.9/0.999, eps 1e-8).  step = Adam step count BEFORE the call.
- * sweep_gamma / sweep_entropy: device [G] per-game values (a config sweep as one batch) or NULL for
- * the scalars.  grad_out [G][P] (optional) receives the clipped gradient. */
+ * price / action / reward: device [G][ld], n <= ld valid entries per row (a replay ring of thrl_mixed can be
+ * passed as it is: ld = buf_len).  sweep_gamma / sweep_entropy: device [G] per-game values (a config sweep as
+ * one batch) or NULL for the scalars.  grad_out [G][P] (optional) receives the clipped gradient. */
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
-                            int32_t step, int32_t n, const double* price, const int32_t* action,
+                            int32_t step, int32_t n, int32_t ld, const double* price, const int32_t* action,
                             const double* reward, double gamma, double entropy_coef, double lr,
                             const double* sweep_gamma, const double* sweep_entropy,
                             float* grad_out, void* stream);
@@ -267,7 +271,7 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
  * thrl_ac_train = train_net (:274-305) AS THE REFERENCE EXECUTES IT: `rewards` is [N] while v and
  * v_prime are [N,1], so advantage = (rewards + gamma*v_prime) - v broadcasts to [N,N]
  * (advantage[i,j] = r_j + gamma*v'_i - v_i); loss = mean_ij(advantage^2 - log p_j(a_j)*advantage)
- * + entropy_coef * (-mean H); v_prime is not detached.  next_price [n][G] = the replayed new_state.
+ * + entropy_coef * (-mean H); v_prime is not detached.  next_price [G][ld] = the replayed new_state.
  */
 size_t thrl_ac_param_count(int n_actions);
 int thrl_ac_init(int n_games, int n_actions, float* params, uint64_t seed, uint64_t game_offset,
@@ -275,7 +279,7 @@ int thrl_ac_init(int n_games, int n_actions, float* params, uint64_t seed, uint6
 int thrl_ac_act(int n_games, int n_actions, const float* params, const double* price, const double* u,
                 int32_t* action_out, float* prob_out, void* stream);
 int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
-                  int32_t step, int32_t n, const double* price, const int32_t* action,
+                  int32_t step, int32_t n, int32_t ld, const double* price, const int32_t* action,
                   const double* reward, const double* next_price, double gamma, double entropy_coef,
                   double lr, const double* sweep_gamma, const double* sweep_entropy, float* grad_out, void* stream);
 /*
@@ -291,13 +295,13 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
  * thrl_cac_train = train_net (:389-416) AS THE REFERENCE EXECUTES IT: rewards / actions [N] against
  *   mu / std / v [N,1] broadcast to [N,N] -- advantage[i,j] = r_j + gamma*v'_i - v_i and
  *   log_prob[i,j] = log N(logit(a_j); mu_i, std_i); loss = mean_ij(advantage^2 - log_prob*advantage)
- *   + entropy_coef*(-mean entropy); clip 1.0; Adam.  action [n][G] float32 as stored by the trainer.
+ *   + entropy_coef*(-mean entropy); clip 1.0; Adam.  action [G][ld] float32 as stored by the trainer.
  */
 #define THRL_CAC_PARAMS 1283
 int thrl_cac_init(int n_games, float* params, uint64_t seed, uint64_t game_offset, int agent, void* stream);
 int thrl_cac_act(int n_games, const float* params, const double* price, const double* u1, const double* u2,
                  float* action_out, float* mu_out, float* std_out, float* v_out, void* stream);
-int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
+int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n, int32_t ld,
                    const double* price, const float* action, const double* reward, const double* next_price,
                    double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
                    float* grad_out, void* stream);
@@ -306,12 +310,13 @@ int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int
  * reference's example configs): trainer.train_one's loop (trainer.py:46-70) with QTable.train_net
  * inside the kernel.  Reinforce / ActorCritic transitions go to that agent's replay buffer; the
  * CALLER runs thrl_nn_reinforce_train / thrl_ac_train when len(memory) >= min_memory and must size n_episodes so that no
- * network update falls inside one call.  Replay buffers are rings [buf_len][G] per agent.
+ * network update falls inside one call.  Replay buffers are rings [G][buf_len] per agent (game-major since ABI v3:
+ * the 16-step flushes of the kernel and a game's whole batch in the update kernels are contiguous).
  */
 typedef struct {
     int32_t kind[THRL_MAXA];             /* 0 = QTable, 1 = Reinforce, 2 = ActorCritic, 3 = CAC */
     const float* nn_params[THRL_MAXA];   /* device [G][P] for the neural agents              */
-    double*  buf_price[THRL_MAXA];       /* device [buf_len][G] state  (trainer.py:62)       */
+    double*  buf_price[THRL_MAXA];       /* device [G][buf_len] state  (trainer.py:62)       */
     int32_t* buf_action[THRL_MAXA];      /* CAC agents: the float32 action's bits             */
     double*  buf_reward[THRL_MAXA];
     double*  buf_nprice[THRL_MAXA];      /* next state                                       */

@@ -10,7 +10,7 @@ for phase, eps_run in (("early", 9), ("after 2000 episodes", 2000), ("after 1000
     mb.run(eps_run, per_game_logs=False)
     # the Reinforce ring holds the prices of the steps since its last update
     n = min(mb.count[1], mb.buf_len[1])
-    pr = mb.buf[1]["price"][:n].cpu().numpy().astype(np.float32)
+    pr = mb.buf[1]["price"][:, :n].t().cpu().numpy().astype(np.float32)       # rings are [G, buf_len]
     d, c32, c64 = [], [], []
     for g in range(64):
         v, cnt = np.unique(pr[:, g], return_counts=True)

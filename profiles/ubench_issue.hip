@@ -26,17 +26,19 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Cls { V_AND, V_AND_E64, V_AND_SGPR, V_ADD_U32, V_MOV, V_LSHL, V_ADD_F32, V_MUL_F32, V_FMAC_F32, V_PK_FMA_F32, V_ADD3, V_CNDMASK_E64, CHAIN4,
+enum Cls { V_AND, V_AND_E64, V_AND_SGPR, V_ADD_U32, V_MOV, V_LSHL, V_ADD_F32, V_MUL_F32, V_FMAC_F32, V_PK_FMA_F32, V_ADD3, V_CNDMASK_E64, V_CNDMASK_E64_VCC, V_CNDMASK_NEWDST, V_CNDMASK_AFTER_CMP, V_MUL_LO_U32, V_MUL_HI_U32, V_XOR, V_CVT_F64_U32, V_CMP_LT_F64, CHAIN4,
            V_ADD_SDWA, V_MAD_U24, V_FMA_F32, V_MAX_DPP, V_MOV_DPP_SHR, V_CNDMASK, V_READLANE, V_WRITELANE, V_PERMLANE32,
            V_FMA_F64, V_ADD_F64, V_MUL_F64, V_MAX3_F32, V_CMP_F32, S_ADD, S_NOP0, S_PACK, DS_READ_U16, DS_READ_B32, DS_READ2_B32, DS_BPERMUTE,
-           MIX_VALU_SALU, MIX_VALU_LDS, N_CLS };
+           MIX_VALU_SALU, MIX_VALU_LDS, MIX_CND_AND_1_1, MIX_CND_AND_1_3, N_CLS };
 static const char* kNames[N_CLS] = {"v_and_b32", "v_and_b32_e64 (VOP3 encoding)", "v_and_b32 (SGPR src0)", "v_add_u32", "v_mov_b32", "v_lshlrev_b32",
-                                    "v_add_f32", "v_mul_f32", "v_fmac_f32 (VOP2)", "v_pk_fma_f32", "v_add3_u32", "v_cndmask_b32_e64 (SGPR-pair mask)",
+                                    "v_add_f32", "v_mul_f32", "v_fmac_f32 (VOP2)", "v_pk_fma_f32", "v_add3_u32", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_cndmask_b32_e64 (mask = vcc)", "v_cndmask_b32 vcc, dst != src", "v_cmp_gt_f32 vcc + 7 v_cndmask_b32 vcc",
+                                    "v_mul_lo_u32", "v_mul_hi_u32", "v_xor_b32", "v_cvt_f64_u32", "v_cmp_lt_f64(->vcc)",
                                     "play chain group: 4 dependent v_readlane + 2 s_pack + 2 v_writelane + s_nop pads (12 instructions = 4 steps)",
                                     "v_add_u32_sdwa", "v_mad_u32_u24", "v_fma_f32", "v_max_f32_dpp(quad_perm)", "v_mov_b32_dpp(row_shr:1)",
                                     "v_cndmask_b32", "v_readlane_b32", "v_writelane_b32", "v_permlane32_swap_b32", "v_fma_f64", "v_add_f64", "v_mul_f64",
                                     "v_max3_f32", "v_cmp_gt_f32(->vcc)", "s_add_u32", "s_nop 0", "s_pack_ll_b32_b16", "ds_read_u16", "ds_read_b32",
-                                    "ds_read2_b32", "ds_bpermute_b32", "mix: v_and_b32 + s_add_u32 (1:1)", "mix: 3 v_and_b32 + 1 ds_read_b32"};
+                                    "ds_read2_b32", "ds_bpermute_b32", "mix: v_and_b32 + s_add_u32 (1:1)", "mix: 3 v_and_b32 + 1 ds_read_b32",
+                                    "mix: v_cndmask_b32 (vcc) + v_and_b32 (1:1)", "mix: v_cndmask_b32 (vcc) + 3 v_and_b32"};
 
 // 8 instructions of class C on 8 independent registers
 #define V8(OP)                                                                                              \
@@ -64,6 +66,11 @@ static const char* kNames[N_CLS] = {"v_and_b32", "v_and_b32_e64 (VOP3 encoding)"
 #define I_ADD3(k)  "v_add3_u32 %" #k ", %" #k ", %8, %8\n\t"
 #define I_CNDE64(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[20:21]\n\t"
 #define I_PKFMA(k) "v_pk_fma_f32 %" #k ", %" #k ", %8, %8\n\t"
+#define I_CNDE64V(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, vcc\n\t"
+#define I_MULLO(k) "v_mul_lo_u32 %" #k ", %" #k ", %8\n\t"
+#define I_MULHI(k) "v_mul_hi_u32 %" #k ", %" #k ", %8\n\t"
+#define I_XOR(k)   "v_xor_b32 %" #k ", %8, %" #k "\n\t"
+#define I_CMP64(k) "v_cmp_lt_f64 vcc, %" #k ", %8\n\t"
 #define I_SDWA(k)  "v_add_u32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
 #define I_MAD(k)   "v_mad_u32_u24 %" #k ", %" #k ", %8, %8\n\t"
 #define I_FMA(k)   "v_fma_f32 %" #k ", %" #k ", %8, %8\n\t"
@@ -123,6 +130,28 @@ __global__ void __launch_bounds__(256) k_issue(int iters, uint64_t* out) {
                              : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
                              : "v"(x) : "s20", "s21", "memory");
             }
+            else if (C == V_CNDMASK_E64_VCC) V8(I_CNDE64V);
+            else if (C == V_CNDMASK_NEWDST) {
+                asm volatile("v_cndmask_b32 %0, %4, %8, vcc\n\tv_cndmask_b32 %1, %5, %8, vcc\n\tv_cndmask_b32 %2, %6, %8, vcc\n\tv_cndmask_b32 %3, %7, %8, vcc\n\t"
+                             "v_cndmask_b32 %4, %0, %8, vcc\n\tv_cndmask_b32 %5, %1, %8, vcc\n\tv_cndmask_b32 %6, %2, %8, vcc\n\tv_cndmask_b32 %7, %3, %8, vcc\n\t"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(x) : "vcc");
+            }
+            else if (C == V_CNDMASK_AFTER_CMP) {
+                asm volatile("v_cmp_gt_f32 vcc, %0, %8\n\t" I_CND(1) I_CND(2) I_CND(3) I_CND(4) I_CND(5) I_CND(6) I_CND(7)
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(x) : "vcc");
+            }
+            else if (C == V_MUL_LO_U32) V8(I_MULLO);
+            else if (C == V_MUL_HI_U32) V8(I_MULHI);
+            else if (C == V_XOR) V8(I_XOR);
+            else if (C == V_CVT_F64_U32) {
+                asm volatile("v_cvt_f64_u32 %0, %4\n\tv_cvt_f64_u32 %1, %5\n\tv_cvt_f64_u32 %2, %6\n\tv_cvt_f64_u32 %3, %7\n\t"
+                             "v_cvt_f64_u32 %0, %5\n\tv_cvt_f64_u32 %1, %6\n\tv_cvt_f64_u32 %2, %7\n\tv_cvt_f64_u32 %3, %4\n\t"
+                             : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+            }
+            else if (C == V_CMP_LT_F64) {
+                asm volatile(I_CMP64(0) I_CMP64(1) I_CMP64(2) I_CMP64(3) I_CMP64(4) I_CMP64(5) I_CMP64(6) I_CMP64(7)
+                             :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(dx) : "vcc");
+            }
             else if (C == V_PK_FMA_F32) D8(I_PKFMA);
             else if (C == CHAIN4) {
                 // the hand-scheduled play-chain group of thrl_wave_kernel.h (chain_group): s <- table_j[s], four steps,
@@ -171,6 +200,14 @@ __global__ void __launch_bounds__(256) k_issue(int iters, uint64_t* out) {
                 asm volatile(I_MIXVS(0) I_MIXVS(1) I_MIXVS(2) I_MIXVS(3)
                              : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+s"(s[0])
                              : "v"(x) : "scc", "memory");
+            }
+            else if (C == MIX_CND_AND_1_1) {
+                asm volatile(I_CND(0) I_AND(1) I_CND(2) I_AND(3) I_CND(4) I_AND(5) I_CND(6) I_AND(7)
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(x) : "vcc");
+            }
+            else if (C == MIX_CND_AND_1_3) {
+                asm volatile(I_CND(0) I_AND(1) I_AND(2) I_AND(3) I_CND(4) I_AND(5) I_AND(6) I_AND(7)
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "v"(x) : "vcc");
             }
             else if (C == MIX_VALU_LDS) {
                 asm volatile("v_and_b32 %0, %8, %0\n\tv_and_b32 %1, %8, %1\n\tv_and_b32 %2, %8, %2\n\tds_read_b32 %3, %9\n\t"

@@ -354,6 +354,7 @@ def test_build_info_names_the_binary(lib):
     info = _lib.build_info()
     assert info["abi"] == 3 and info["ablate"] == 0 and lib.thrl_ablate_mask() == 0
     assert info["src"] == build.source_hash() and re.fullmatch(r"[0-9a-f]{12}", info["src"])
+    assert info["wave"] == build.source_hash(build.WAVE_FILES) and info["nn"] == build.source_hash(build.NN_FILES)
     assert info["path"].endswith("libthrl_hip.so")
 
 

@@ -156,7 +156,7 @@ def load():
     L.thrl_nn_act.restype = ctypes.c_int
     L.thrl_nn_act.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     L.thrl_nn_reinforce_train.restype = ctypes.c_int
-    L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp,
+    L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, vp, vp, vp,
                                           dbl, dbl, dbl, vp, vp, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
     L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]
@@ -165,7 +165,7 @@ def load():
     L.thrl_cac_act.restype = ctypes.c_int
     L.thrl_cac_act.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.thrl_cac_train.restype = ctypes.c_int
-    L.thrl_cac_train.argtypes = [ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
+    L.thrl_cac_train.argtypes = [ctypes.c_int, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp,
                                  ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
     L.thrl_ac_param_count.restype = ctypes.c_size_t
     L.thrl_ac_param_count.argtypes = [ctypes.c_int]
@@ -174,7 +174,7 @@ def load():
     L.thrl_ac_act.restype = ctypes.c_int
     L.thrl_ac_act.argtypes = L.thrl_nn_act.argtypes
     L.thrl_ac_train.restype = ctypes.c_int
-    L.thrl_ac_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, vp, vp, vp, vp,
+    L.thrl_ac_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp,
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
     L.thrl_mixed_episodes.restype = ctypes.c_int
     L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
@@ -188,7 +188,7 @@ def build_info():
     """dict(path, abi, ablate, src) of the loaded library (thrl_build_info)."""
     L = load()
     d = dict(kv.split("=", 1) for kv in L.thrl_build_info().decode().split(";"))
-    return dict(path=LIB_PATH, abi=int(d["abi"]), ablate=int(d["ablate"]), src=d["src"])
+    return dict(path=LIB_PATH, abi=int(d["abi"]), ablate=int(d["ablate"]), src=d["src"], wave=d.get("wave"), nn=d.get("nn"))
 
 
 def check(rc, what):

@@ -39,12 +39,17 @@ def up_to_date(lib=LIB):
     return all(os.path.getmtime(d) <= t for d in _deps())
 
 
-def source_hash():
-    """sha1 (12 hex digits) over the kernel sources, headers and compiler flags: what thrl_build_info() reports
-    as `src=` and profiles/traffic.json records, so bench.py can tell when its PMC constants were collected on
-    another kernel."""
+WAVE_FILES = ["thrl_wave_kernel.h", "thrl_wave_f32.hip", "thrl_wave_lut.h", "thrl_kernels.h", "thrl_device.h"]
+NN_FILES = ["thrl_mixed.hip", "thrl_nn.hip", "thrl_policy.h", "thrl_cac.h", "thrl_cac.hip", "thrl_kernels.h", "thrl_device.h"]
+
+
+def source_hash(files=None):
+    """sha1 (12 hex digits) over kernel sources, headers and compiler flags.  thrl_build_info() reports three:
+    `src=` everything, `wave=` what the headline kernel k_wave_episodes<float,...> is compiled from, `nn=` the
+    neural-agent kernels.  profiles/traffic.json / nn_traffic.json record the hash of the binary their PMC
+    constants were collected on, so bench.py can tell when they are stale."""
     h = hashlib.sha1(" ".join(FLAGS).encode())
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(files if files is not None else SOURCES + HEADERS):
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:12]
@@ -63,14 +68,15 @@ def build(force=False, verbose=False, ablate=0, out=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 
-    src_hash = source_hash()
+    src_hash, wave_hash, nn_hash = source_hash(), source_hash(WAVE_FILES), source_hash(NN_FILES)
 
     def compile_one(src):
         flags = list(cflags)
         if ablate and src == "thrl_wave_f32.hip":
             flags.append("-DTHRL_ABLATE=%d" % ablate)
         if src == "thrl_api.hip":           # thrl_build_info(): which binary is this
-            flags += ["-DTHRL_BUILD_ABLATE=%d" % ablate, '-DTHRL_SRC_HASH="%s"' % src_hash]
+            flags += ["-DTHRL_BUILD_ABLATE=%d" % ablate, '-DTHRL_SRC_HASH="%s"' % src_hash,
+                      '-DTHRL_WAVE_HASH="%s"' % wave_hash, '-DTHRL_NN_HASH="%s"' % nn_hash]
         key = hashlib.sha1((" ".join(flags) + hipcc).encode()).hexdigest()[:10]
         obj = os.path.join(OBJ_DIR, "%s-%s.o" % (src.replace(".hip", ""), key))
         path = os.path.join(CSRC, src)

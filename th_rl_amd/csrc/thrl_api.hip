@@ -289,10 +289,17 @@ const char* thrl_last_error(void) { return g_err; }
 #ifndef THRL_SRC_HASH
 #define THRL_SRC_HASH "unknown"
 #endif
+#ifndef THRL_WAVE_HASH
+#define THRL_WAVE_HASH "unknown"
+#endif
+#ifndef THRL_NN_HASH
+#define THRL_NN_HASH "unknown"
+#endif
 #define THRL_STR2(x) #x
 #define THRL_STR(x) THRL_STR2(x)
 const char* thrl_build_info(void) {
-    return "abi=" THRL_STR(THRL_ABI_VERSION) ";ablate=" THRL_STR(THRL_BUILD_ABLATE) ";src=" THRL_SRC_HASH;
+    return "abi=" THRL_STR(THRL_ABI_VERSION) ";ablate=" THRL_STR(THRL_BUILD_ABLATE) ";src=" THRL_SRC_HASH
+           ";wave=" THRL_WAVE_HASH ";nn=" THRL_NN_HASH;
 }
 int thrl_ablate_mask(void) { return THRL_BUILD_ABLATE; }
 
@@ -673,7 +680,7 @@ int thrl_ac_act(int n_games, int n_actions, const float* params, const double* p
 }
 
 int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
-                  const double* price, const int32_t* action, const double* reward, const double* next_price,
+                  int32_t ld, const double* price, const int32_t* action, const double* reward, const double* next_price,
                   double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
                   float* grad_out, void* stream) {
     int rc = nn_check(n_games, n_actions);
@@ -684,7 +691,8 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
         return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions out of [2,%d]", n, THRL_NN_MAX_TRANSITIONS);
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
     if (nn_train_lds_bytes(n_actions, n, 1) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
-    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, next_price,
+    if (ld < n) return fail(THRL_ERR_BAD_CONFIG, "ld=%d < n=%d", ld, n);
+    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, ld, price, action, reward, next_price,
                                   (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train<AC> launch") : THRL_OK;
@@ -701,7 +709,7 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
 }
 
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step,
-                            int32_t n, const double* price, const int32_t* action, const double* reward,
+                            int32_t n, int32_t ld, const double* price, const int32_t* action, const double* reward,
                             double gamma, double entropy_coef, double lr, const double* sweep_gamma,
                             const double* sweep_entropy, float* grad_out, void* stream) {
     int rc = nn_check(n_games, n_actions);
@@ -711,7 +719,8 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
         return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions out of [2,%d]", n, THRL_NN_MAX_TRANSITIONS);
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
     if (nn_train_lds_bytes(n_actions, n, 0) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
-    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, price, action, reward, nullptr,
+    if (ld < n) return fail(THRL_ERR_BAD_CONFIG, "ld=%d < n=%d", ld, n);
+    const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, ld, price, action, reward, nullptr,
                                   (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
@@ -793,7 +802,7 @@ int thrl_cac_act(int n_games, const float* params, const double* price, const do
     return e ? hip_fail(e, "k_cac_act launch") : THRL_OK;
 }
 
-int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n,
+int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int32_t step, int32_t n, int32_t ld,
                    const double* price, const float* action, const double* reward, const double* next_price,
                    double gamma, double entropy_coef, double lr, const double* sweep_gamma, const double* sweep_entropy,
                    float* grad_out, void* stream) {
@@ -803,7 +812,8 @@ int thrl_cac_train(int n_games, float* params, float* adam_m, float* adam_v, int
     if (n < 2 || cac_train_lds_bytes(n) > 160 * 1024)
         return fail(THRL_ERR_UNSUPPORTED, "n=%d transitions: need 2 <= n and the batch in LDS (n <= ~5600)", n);
     if (step < 0) return fail(THRL_ERR_BAD_CONFIG, "step < 0");
-    const int e = launch_cac_train(n_games, params, adam_m, adam_v, step, n, price, action, reward, next_price,
+    if (ld < n) return fail(THRL_ERR_BAD_CONFIG, "ld=%d < n=%d", ld, n);
+    const int e = launch_cac_train(n_games, params, adam_m, adam_v, step, n, ld, price, action, reward, next_price,
                                    (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
                                    (hipStream_t)stream);
     return e ? hip_fail(e, "k_cac_train launch") : THRL_OK;

@@ -85,7 +85,7 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 // The per-row sums S0 = sum_j adv, S1 = sum_j adv*(y_j-mu_i), S2 = sum_j adv*(y_j-mu_i)^2 have closed
 // forms in the five batch sums R, Y, YY, RY, RYY (float64 here), so the update is O(N).
 __global__ void __launch_bounds__(256) k_cac_train(int G, float* __restrict__ params, float* __restrict__ adam_m,
-        float* __restrict__ adam_v, int step, int N, const double* __restrict__ price, const float* __restrict__ action,
+        float* __restrict__ adam_v, int step, int N, int ld, const double* __restrict__ price, const float* __restrict__ action,
         const double* __restrict__ reward, const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
         const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cac[];
@@ -103,9 +103,11 @@ __global__ void __launch_bounds__(256) k_cac_train(int G, float* __restrict__ pa
     ws[3 * kH + tid] = w[oWstd + tid]; ws[4 * kH + tid] = w[oWv + tid];
     const float bmu = w[oBmu], bstd = w[oBstd], bv = w[oBv];
     for (int n = tid; n < N; n += 256) {
-        xs[n] = (float)price[(size_t)n * G + g]; xps[n] = (float)nprice[(size_t)n * G + g];
-        rs[n] = (float)reward[(size_t)n * G + g];
-        const float a2 = 5e-5f + (1.0f - 1e-4f) * action[(size_t)n * G + g];
+        // the replayed transitions of game g are one contiguous row [ld] per array (game-major rings)
+        const size_t m = (size_t)g * ld + n;
+        xs[n] = (float)price[m]; xps[n] = (float)nprice[m];
+        rs[n] = (float)reward[m];
+        const float a2 = 5e-5f + (1.0f - 1e-4f) * action[m];
         ys[n] = logf(a2 / (1.0f - a2));
     }
     __syncthreads();
@@ -193,14 +195,14 @@ int launch_cac_act(int G, const float* params, const double* price, const double
     return (int)hipGetLastError();
 }
 size_t cac_train_lds_bytes(int N) { return 4 * sizeof(double) + sizeof(float) * (8 + 5 * (size_t)kH + 7 * (size_t)N); }
-int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, const double* price, const float* action,
+int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, int ld, const double* price, const float* action,
                      const double* reward, const double* nprice, float gamma, float ent, float lr,
                      const double* gamma_g, const double* ent_g, float* grad, hipStream_t s) {
     const size_t lds = cac_train_lds_bytes(N);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cac_train), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_cac_train, dim3(G), dim3(256), lds, s, G, params, m, v, step, N, price, action, reward, nprice,
+    hipLaunchKernelGGL(k_cac_train, dim3(G), dim3(256), lds, s, G, params, m, v, step, N, ld, price, action, reward, nprice,
                        gamma, ent, lr, gamma_g, ent_g, grad);
     return (int)hipGetLastError();
 }

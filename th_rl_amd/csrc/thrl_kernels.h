@@ -152,7 +152,7 @@ struct MixedArgs {
     void* q; int32_t* counter; double* state;
     const float* nn_params[THRL_MAXA];    // [G][nn_stride] per Reinforce / ActorCritic agent
     int32_t nn_stride[THRL_MAXA];
-    double* buf_price[THRL_MAXA]; int32_t* buf_action[THRL_MAXA];      // replay buffers [buf_len][G]
+    double* buf_price[THRL_MAXA]; int32_t* buf_action[THRL_MAXA];      // replay rings [G][buf_len] (game-major)
     double* buf_reward[THRL_MAXA]; double* buf_nprice[THRL_MAXA]; double* buf_ov[THRL_MAXA];
     int32_t buf_len[THRL_MAXA]; int32_t min_memory[THRL_MAXA]; int32_t count0[THRL_MAXA];
     double eps0[THRL_MAXA];
@@ -176,7 +176,7 @@ int launch_nn_act(int G, int A, const float* params, int P, const double* price,
                   float* prob, hipStream_t s);
 size_t nn_train_lds_bytes(int A, int N, int value_head);
 // nprice != NULL: ActorCritic update (value head, params stride P + 257); NULL: Reinforce
-int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
+int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, int ld, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
                     const double* gamma_g, const double* ent_g,      // per-game gamma / entropy coefficient [G] or null
                     float* grad,
@@ -186,7 +186,7 @@ int launch_cac_init(int G, float* params, uint64_t seed, uint64_t off, int agent
 int launch_cac_act(int G, const float* params, const double* price, const double* u1, const double* u2, float* action,
                    float* mu, float* sd, float* v, hipStream_t s);
 size_t cac_train_lds_bytes(int N);
-int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, const double* price, const float* action,
+int launch_cac_train(int G, float* params, float* m, float* v, int step, int N, int ld, const double* price, const float* action,
                      const double* reward, const double* nprice, float gamma, float ent, float lr,
                      const double* gamma_g, const double* ent_g, float* grad, hipStream_t s);
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,

@@ -8,7 +8,8 @@
 //   * QTable tables live in LDS for the launch (row argmax / row max are one lane per action);
 //   * Philox draws are produced 64 steps at a time, one step per lane; the scaled-action tables
 //     and the two log accumulators are lane-parallel, so one float64 division per step remains;
-//   * Reinforce transitions are appended to that agent's HBM replay ring; the host launches
+//   * Reinforce transitions are appended to that agent's HBM replay ring ([G][buf_len]: a game's slots are
+//     contiguous, for the 16-step flushes here and for the update kernels); the host launches
 //     k_nn_reinforce_train when an update is due and sizes n_episodes so none falls inside.
 // Same Philox streams and the same arithmetic as the unfused operator loop: bit-identical.
 #include "thrl_cac.h"
@@ -213,7 +214,7 @@ k_mixed_wave(const MixedArgs a) {
             // ---- memory.append (trainer.py:62), lane i for agent i
             if (kLanePointers) {
                 if (lane < N && cap_l > 0) {
-                    const size_t m = (size_t)widx_l * G + g;
+                    const size_t m = (size_t)g * cap_l + widx_l;
                     my_bp[m] = price; my_ba[m] = act_l;
                     my_br[m] = rew_l; my_bn[m] = next_price;
                 }
@@ -236,7 +237,7 @@ k_mixed_wave(const MixedArgs a) {
                         if (lane < nb && lane >= nb - cap) {
                             int slot = w0 + lane;
                             while (slot >= cap) slot -= cap;
-                            const size_t m = (size_t)slot * G + g;
+                            const size_t m = (size_t)g * cap + slot;      // 16 consecutive slots: coalesced
                             a.buf_price[i][m] = st_price[lane];
                             a.buf_action[i][m] = st_act[lane * N + i];
                             a.buf_reward[i][m] = st_rew[lane * N + i];
@@ -277,7 +278,7 @@ k_mixed_wave(const MixedArgs a) {
                 for (int base = 0; base < len; base += 64) {            // old_value snapshot (agents.py:67)
                     const int j = base + lane;
                     if (j < len) {
-                        const size_t m = (size_t)((start + j) % cap) * G + g;
+                        const size_t m = (size_t)g * cap + (start + j) % cap;
                         bo[m] = (double)tab[encode64(bp[m], p) * A + ba[m]];
                     }
                 }
@@ -285,7 +286,7 @@ k_mixed_wave(const MixedArgs a) {
                     const int j = base + lane;
                     int st = 0, ns = 0, ac = 0; double re = 0.0; T ov = (T)0;
                     if (j < len) {
-                        const size_t m = (size_t)((start + j) % cap) * G + g;
+                        const size_t m = (size_t)g * cap + (start + j) % cap;
                         st = encode64(bp[m], p); ns = encode64(bn[m], p);
                         ac = ba[m]; re = br[m]; ov = (T)bo[m];
                     }

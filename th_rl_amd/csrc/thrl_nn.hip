@@ -79,7 +79,7 @@ __device__ __forceinline__ int train_xs_len(int N) { return (N + kChunk - 1) / k
 // detached) and its column sums the actor (weight r_j + C/N in place of Reinforce's return).
 template <int kPad, bool AC>
 __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
-        float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N,
+        float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N, int ld,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
         const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
         const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out) {
@@ -110,15 +110,18 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
     float* w = params + (int64_t)g * P;
+    // the replayed transitions of game g: one contiguous row [ld] per array (game-major rings, ABI v3)
+    price += (size_t)g * ld; reward += (size_t)g * ld; action += (size_t)g * ld;
+    if (AC) nprice += (size_t)g * ld;
 
     for (int k = 0; k < A; k++) W2t[tid * kPad + k] = w[2 * kH + k * kH + tid];
     for (int k = A; k < kPad; k++) W2t[tid * kPad + k] = 0.0f;
     w1s[tid] = w[tid]; b1s[tid] = w[kH + tid];
     if (tid < kMaxA) b2s[tid] = tid < A ? w[2 * kH + A * kH + tid] : 0.0f;
     for (int n = tid; n < NX; n += 256) {
-        xs[n] = n < N ? (float)price[(size_t)n * G + g] : 0.0f;
-        Gs[n] = n < N ? (float)reward[(size_t)n * G + g] : 0.0f;
-        if (AC) xps[n] = n < N ? (float)nprice[(size_t)n * G + g] : 0.0f;
+        xs[n] = n < N ? (float)price[n] : 0.0f;
+        Gs[n] = n < N ? (float)reward[n] : 0.0f;
+        if (AC) xps[n] = n < N ? (float)nprice[n] : 0.0f;
     }
     if (AC) wvs[tid] = w[Pp + tid];
     __syncthreads();
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             for (int n = tid; n < N; n += 256) {
                 const int u = (int)uid[n] - c0;
                 if (u >= 0 && u < cn) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[(size_t)n * G + g]]),
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[n]]),
                               (unsigned long long)llrint((double)Gs[n] * 1099511627776.0));
                     atomicAdd(&ucnt[u], 1);
                 }
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                     zz[k] = k < A ? (zz[k] * SG - (float)((double)row[k] * 0x1p-40) + cnt * (ent_coef * zz[k] * (lp[k] + Hn))) * invN
                                   : 0.0f;
             } else {
-                const int a_n = action[(size_t)n * G + g];
+                const int a_n = action[n];
                 const float Gn = Gs[n];
 #pragma unroll
                 for (int k = 0; k < kPad; k++)
@@ -466,33 +469,48 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     const float norm = sqrtf(block_sum(sq, red));
     const float coef = fminf(1.0f, 1.0f / (norm + 1e-6f));
 
-    // Adam (torch.optim.Adam defaults, lr from the caller)
+    // Adam (torch.optim.Adam defaults, lr from the caller).  The gradient sits in the registers of the pass-B owners
+    // (128 threads x 46 parameters); updating from there is 46 dependent HBM round trips per block -- the phase was
+    // ~80 % of the kernel.  So it is staged in LDS and all 256 threads sweep the parameter vector in order:
+    // coalesced loads of m, v, w, eight per thread in flight, three round trips for the 5,909 parameters.
     const float t = (float)(step + 1);
     const float bc1 = 1.0f - powf(0.9f, t), bc2s = sqrtf(1.0f - powf(0.999f, t));
     const float step_size = lr / bc1;
     float* mg = adam_m + (int64_t)g * P;
     float* vg = adam_v + (int64_t)g * P;
-    auto upd = [&](int idx, float grad) {
-        grad *= coef;
-        if (grad_out) grad_out[(int64_t)g * P + idx] = grad;
-        const float m = 0.9f * mg[idx] + 0.1f * grad;
-        const float v = 0.999f * vg[idx] + 0.001f * grad * grad;
-        mg[idx] = m; vg[idx] = v;
-        w[idx] = w[idx] - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
-    };
+    float* gl = comb + 128 * kRow + 256;                    // [P] unscaled gradient (behind the combine scratch)
     if (half == 0) {
-        upd(ja, gw1a); upd(jb, gw1b);
-        upd(kH + ja, gb1a); upd(kH + jb, gb1b);
+        gl[ja] = gw1a; gl[jb] = gw1b; gl[kH + ja] = gb1a; gl[kH + jb] = gb1b;
 #pragma unroll
         for (int p = 0; p < kPad / 2; p++) {
-            if (2 * p < A) { upd(2 * kH + (2 * p) * kH + ja, gWa[p].x); upd(2 * kH + (2 * p) * kH + jb, gWb[p].x); }
-            if (2 * p + 1 < A) { upd(2 * kH + (2 * p + 1) * kH + ja, gWa[p].y); upd(2 * kH + (2 * p + 1) * kH + jb, gWb[p].y); }
+            if (2 * p < A) { gl[2 * kH + (2 * p) * kH + ja] = gWa[p].x; gl[2 * kH + (2 * p) * kH + jb] = gWb[p].x; }
+            if (2 * p + 1 < A) { gl[2 * kH + (2 * p + 1) * kH + ja] = gWa[p].y; gl[2 * kH + (2 * p + 1) * kH + jb] = gWb[p].y; }
         }
+        if (AC) { gl[Pp + ja] = gwva; gl[Pp + jb] = gwvb; }
     }
-    if (tid < A) upd(2 * kH + A * kH + tid, gb2);
-    if (AC) {
-        if (half == 0) { upd(Pp + ja, gwva); upd(Pp + jb, gwvb); }
-        if (tid == 255) upd(Pp + kH, gbv);
+    if (tid < A) gl[2 * kH + A * kH + tid] = gb2;
+    if (AC && tid == 255) gl[Pp + kH] = gbv;
+    __syncthreads();
+    constexpr int kB = 8;
+    for (int i0 = tid; i0 < P; i0 += 256 * kB) {
+        float mm[kB], vv[kB], ww[kB], gg[kB];
+#pragma unroll
+        for (int b = 0; b < kB; b++) {
+            const int idx = min(i0 + 256 * b, P - 1);
+            mm[b] = mg[idx]; vv[b] = vg[idx]; ww[b] = w[idx]; gg[b] = gl[idx];
+        }
+#pragma unroll
+        for (int b = 0; b < kB; b++) {
+            const int idx = i0 + 256 * b;
+            if (idx < P) {
+                const float grad = gg[b] * coef;
+                if (grad_out) grad_out[(int64_t)g * P + idx] = grad;
+                const float m = 0.9f * mm[b] + 0.1f * grad;
+                const float v = 0.999f * vv[b] + 0.001f * grad * grad;
+                mg[idx] = m; vg[idx] = v;
+                w[idx] = ww[b] - step_size * (m / (sqrtf(v) / bc2s + 1e-8f));
+            }
+        }
     }
 }
 
@@ -537,10 +555,13 @@ int launch_nn_act(int G, int A, const float* params, int P, const double* price,
 size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
-    return sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
+    const size_t work = sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
                             (value_head ? 2 * nx + kH : nx / 2 + kHash + kUmax + 8 + kHash + kHash / 2 + 2 * (size_t)kUmax * pad));
+    // the Adam sweep stages the gradient [P] behind the combine scratch [128][2 pad + 6] + [256]
+    const size_t stage = sizeof(float) * (128 * (2 * pad + 6) + 256 + (size_t)(2 * kH + A * kH + A + (value_head ? kH + 1 : 0)));
+    return work > stage ? work : stage;
 }
-int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, const double* price,
+int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, int ld, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
                     const double* gamma_g, const double* ent_g, float* grad, hipStream_t s) {
     const size_t lds = nn_train_lds_bytes(A, N, nprice != nullptr);
@@ -548,7 +569,7 @@ int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, i
                        : (A <= 24 ? k_nn_reinforce_train<24, false> : k_nn_reinforce_train<32, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, price, action, reward, nprice,
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, ld, price, action, reward, nprice,
                        gamma, ent, lr, gamma_g, ent_g, grad);
     return (int)hipGetLastError();
 }

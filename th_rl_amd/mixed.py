@@ -82,11 +82,13 @@ class MixedGameBatch:
         self.buf_len = [min(self.cap[i], self.min_memory[i] + self.T) if self.cap[i] >= self.min_memory[i] else self.cap[i]
                         for i in range(self.N)]
         with torch.cuda.device(self.device):
-            self.buf = [dict(price=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
-                             action=torch.zeros((max(n, 1), self.G), device=self.device,
+            # replay rings, game-major [G, buf_len] (include/thrl.h, ABI v3): a game's slots are contiguous, so the
+            # episode kernel's 16-step flushes coalesce and an update kernel reads a game's whole batch as one row
+            self.buf = [dict(price=torch.zeros((self.G, max(n, 1)), dtype=torch.float64, device=self.device),
+                             action=torch.zeros((self.G, max(n, 1)), device=self.device,
                                                 dtype=torch.float32 if self.kinds[i] == "CAC" else torch.int32),
-                             reward=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device),
-                             nprice=torch.zeros((max(n, 1), self.G), dtype=torch.float64, device=self.device))
+                             reward=torch.zeros((self.G, max(n, 1)), dtype=torch.float64, device=self.device),
+                             nprice=torch.zeros((self.G, max(n, 1)), dtype=torch.float64, device=self.device))
                         for i, n in enumerate(self.buf_len)]
         # a network update replays the whole buffer: T * ceil(min_memory / T) transitions (the check runs at
         # episode ends only).  The update kernels keep the batch in LDS, so reject a config that cannot
@@ -243,7 +245,7 @@ class MixedGameBatch:
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
         """Everything a continued run needs (plain tensors / numbers: loads with weights_only=True)."""
-        return dict(version=1, kind="mixed", n_games=self.G, kinds=list(self.kinds), shapes=[list(x) for x in self.shapes],
+        return dict(version=2, kind="mixed", n_games=self.G, kinds=list(self.kinds), shapes=[list(x) for x in self.shapes],
                     dtype=self.dtype, seed=self.seed, game_offset=self.game_offset, episode=self.episode,
                     eps=[float(x) for x in self.eps], count=[int(x) for x in self.count],
                     q=self.q.cpu(), counter=self.counter.cpu(), state=self.state.cpu(),
@@ -265,8 +267,8 @@ class MixedGameBatch:
         self.episode = int(sd["episode"])
         self.seed, self.game_offset = int(sd["seed"]), int(sd["game_offset"])
         for b, src in zip(self.buf, sd["buffers"]):
-            for k in b:
-                b[k].copy_(src[k])
+            for k in b:            # version 1 checkpoints hold the rings transition-major [buf_len, G]
+                b[k].copy_(src[k].t() if int(sd.get("version", 1)) < 2 else src[k])
         if sd.get("sweep"):
             self.set_sweep({k: v.numpy() for k, v in sd["sweep"].items()})
         for i, rb in self.nn.items():
@@ -287,23 +289,24 @@ class MixedGameBatch:
             return
         pos = self.count[i] % cap
         b = self.buf[i]
-        b["price"][pos].copy_(price); b["action"][pos].copy_(action)
-        b["reward"][pos].copy_(reward); b["nprice"][pos].copy_(nprice)
+        b["price"][:, pos].copy_(price); b["action"][:, pos].copy_(action)
+        b["reward"][:, pos].copy_(reward); b["nprice"][:, pos].copy_(nprice)
         self.count[i] += 1
         if self.count[i] >= 2 * cap:
             self.count[i] -= cap
 
     def _ordered(self, i):
-        """Buffer contents in insertion order (deque semantics), as contiguous [n, G] tensors."""
+        """Buffer contents in insertion order (deque semantics) as [G, n] tensors: views of the rings when the
+        ring has not wrapped (the usual case: no copy, the update kernels take the row pitch), else gathered."""
         torch = _torch()
         cap = self.buf_len[i]
         n = min(self.count[i], cap)
         start = 0 if self.count[i] <= cap else self.count[i] % cap
         b = self.buf[i]
         if start == 0:
-            return n, {k: v[:n].contiguous() for k, v in b.items()}
+            return n, {k: v[:, :n] for k, v in b.items()}
         idx = (torch.arange(n, device=self.device) + start) % cap
-        return n, {k: v.index_select(0, idx).contiguous() for k, v in b.items()}
+        return n, {k: v.index_select(1, idx).contiguous() for k, v in b.items()}
 
     def run(self, n_episodes, fused=None, per_game_logs=True):
         """n_episodes for all games.  fused=True: thrl_mixed_episodes, one launch per run of episodes
@@ -383,7 +386,7 @@ class MixedGameBatch:
                     if self.kinds[i] != "QTable":
                         n, b = self._ordered(i)
                         if n >= self.min_memory[i] and n > 0:
-                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"])
+                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"], rows=True)
                             self.count[i] = 0
             torch.cuda.synchronize(self.device)
             out = dict(kernel="mixed-fused", reward_log=rmean.cpu().numpy(), action_log=amean.cpu().numpy())
@@ -455,13 +458,14 @@ class MixedGameBatch:
                     if n >= self.min_memory[i] and n > 0:
                         if self.kinds[i] == "QTable":
                             scratch = torch.zeros((n, G), dtype=torch.float64, device=self.device)
+                            bt = {k: v.t().contiguous() for k, v in b.items()}      # the operator form is [n][G]
                             _lib.check(L.thrl_op_td_update(cfg, i, self._p(self.q), self._p(self.counter), n,
-                                                           self._p(b["price"]), self._p(b["action"]), self._p(b["reward"]),
-                                                           self._p(b["nprice"]), self._p(scratch), self._stream()),
+                                                           self._p(bt["price"]), self._p(bt["action"]), self._p(bt["reward"]),
+                                                           self._p(bt["nprice"]), self._p(scratch), self._stream()),
                                        "thrl_op_td_update")
                             torch.cuda.synchronize(self.device)
                         else:
-                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"])
+                            self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"], rows=True)
                         self.count[i] = 0
                     if self.kinds[i] == "QTable":                # epsilon decays on every call (agents.py:78)
                         self.eps[i] = self.cfg.eps_end[i] + (self.eps[i] - self.cfg.eps_end[i]) * self.cfg.eps_step[i]

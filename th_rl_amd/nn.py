@@ -85,17 +85,35 @@ class ReinforceBatch:
                        self._fn["act"])
         return (out, probs) if want_probs else out
 
-    def train(self, price, action, reward, want_grad=False, next_price=None):
-        """One train_net update on n transitions per game: arrays [n, G]."""
+    def _rows(self, a, dtype, rows):
+        """The library's layout of a replayed batch: [G, ld] game-major, the first n entries of a row valid.
+        rows=False: `a` is [n, G] (transition-major, the reference's replay() order) and is transposed;
+        rows=True: `a` is a device tensor [G, n] already -- possibly a view of a replay ring [G, buf_len]
+        (unit stride along the row), passed as it is with ld = its row pitch."""
+        torch = _torch()
+        if rows:
+            if not (isinstance(a, torch.Tensor) and a.dim() == 2 and a.shape[0] == self.G and a.dtype == dtype
+                    and a.device == self.device and (a.shape[1] <= 1 or a.stride(1) == 1)):
+                raise ThrlError("rows=True needs a %s device tensor [G, n] with unit stride along the row" % dtype)
+            return a, int(a.shape[1]), int(a.stride(0)) if self.G > 1 else int(a.shape[1])
+        t = self._dev(a, dtype)
+        n = t.shape[0]
+        t = t.reshape(n, self.G).t().contiguous()
+        return t, int(n), int(n)
+
+    def train(self, price, action, reward, want_grad=False, next_price=None, rows=False):
+        """One train_net update on n transitions per game: arrays [n, G] (rows=True: device tensors [G, n], see
+        _rows -- the fused loop hands its replay rings over without a copy)."""
         torch = _torch()
         with torch.cuda.device(self.device):
-            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
-            d_a = self._dev(action, torch.int32).reshape(n, self.G)
-            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
-            d_p = d_p.reshape(n, self.G)
+            d_p, n, ld = self._rows(price, torch.float64, rows)
+            d_a, _, lda = self._rows(action, torch.int32, rows)
+            d_r, _, ldr = self._rows(reward, torch.float64, rows)
+            if not (ld == lda == ldr):
+                raise ThrlError("price / action / reward rows must share one pitch")
             grad = torch.zeros_like(self.params) if want_grad else None
             _lib.check(self.L.thrl_nn_reinforce_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
-                                                      self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a),
+                                                      self._p(self.adam_v), self.step, n, ld, self._p(d_p), self._p(d_a),
                                                       self._p(d_r), self.gamma, self.entropy, self.lr,
                                                       self._p(self.gamma_g), self._p(self.entropy_g),
                                                       self._p(grad), self._stream()), "thrl_nn_reinforce_train")
@@ -110,19 +128,20 @@ class ActorCriticBatch(ReinforceBatch):
     value_head = True
     _fn = dict(count="thrl_ac_param_count", init="thrl_ac_init", act="thrl_ac_act")
 
-    def train(self, price, action, reward, want_grad=False, next_price=None):
+    def train(self, price, action, reward, want_grad=False, next_price=None, rows=False):
         torch = _torch()
         if next_price is None:
             raise ThrlError("ActorCriticBatch.train needs next_price (the replayed new_state)")
         with torch.cuda.device(self.device):
-            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
-            d_a = self._dev(action, torch.int32).reshape(n, self.G)
-            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
-            d_n = self._dev(next_price, torch.float64).reshape(n, self.G)
-            d_p = d_p.reshape(n, self.G)
+            d_p, n, ld = self._rows(price, torch.float64, rows)
+            d_a, _, lda = self._rows(action, torch.int32, rows)
+            d_r, _, ldr = self._rows(reward, torch.float64, rows)
+            d_n, _, ldn = self._rows(next_price, torch.float64, rows)
+            if not (ld == lda == ldr == ldn):
+                raise ThrlError("price / action / reward / next_price rows must share one pitch")
             grad = torch.zeros_like(self.params) if want_grad else None
             _lib.check(self.L.thrl_ac_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
-                                            self._p(self.adam_v), self.step, n, self._p(d_p), self._p(d_a), self._p(d_r),
+                                            self._p(self.adam_v), self.step, n, ld, self._p(d_p), self._p(d_a), self._p(d_r),
                                             self._p(d_n), self.gamma, self.entropy, self.lr, self._p(self.gamma_g),
                                             self._p(self.entropy_g), self._p(grad), self._stream()), "thrl_ac_train")
             torch.cuda.synchronize(self.device)
@@ -155,6 +174,7 @@ class CACBatch:
     _stream = ReinforceBatch._stream
     _p = staticmethod(ReinforceBatch._p)
     _dev = ReinforceBatch._dev
+    _rows = ReinforceBatch._rows
     set_params = ReinforceBatch.set_params
 
     def init(self):
@@ -179,19 +199,20 @@ class CACBatch:
                                            self._stream()), "thrl_cac_act")
         return (out, heads) if want_heads else out
 
-    def train(self, price, action, reward, want_grad=False, next_price=None):
+    def train(self, price, action, reward, want_grad=False, next_price=None, rows=False):
         torch = _torch()
         if next_price is None:
             raise ThrlError("CACBatch.train needs next_price (the replayed new_state)")
         with torch.cuda.device(self.device):
-            d_p = self._dev(price, torch.float64); n = d_p.shape[0]
-            d_a = self._dev(action, torch.float32).reshape(n, self.G)
-            d_r = self._dev(reward, torch.float64).reshape(n, self.G)
-            d_n = self._dev(next_price, torch.float64).reshape(n, self.G)
-            d_p = d_p.reshape(n, self.G)
+            d_p, n, ld = self._rows(price, torch.float64, rows)
+            d_a, _, lda = self._rows(action, torch.float32, rows)
+            d_r, _, ldr = self._rows(reward, torch.float64, rows)
+            d_n, _, ldn = self._rows(next_price, torch.float64, rows)
+            if not (ld == lda == ldr == ldn):
+                raise ThrlError("price / action / reward / next_price rows must share one pitch")
             grad = torch.zeros_like(self.params) if want_grad else None
             _lib.check(self.L.thrl_cac_train(self.G, self._p(self.params), self._p(self.adam_m), self._p(self.adam_v),
-                                             self.step, n, self._p(d_p), self._p(d_a), self._p(d_r), self._p(d_n),
+                                             self.step, n, ld, self._p(d_p), self._p(d_a), self._p(d_r), self._p(d_n),
                                              self.gamma, self.entropy, self.lr, self._p(self.gamma_g), self._p(self.entropy_g),
                                              self._p(grad), self._stream()),
                        "thrl_cac_train")

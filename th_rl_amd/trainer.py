@@ -67,6 +67,19 @@ def resume_is_gamebatch(path):
     return torch.load(path, weights_only=True).get("kind") != "mixed"
 
 
+def _eps_of_game0(batch):
+    """Epsilon per agent as game 0 has it: with a per-game epsilon sweep the schedule lives on the device
+    (batch.sweep['eps'][agent, game], decayed in the kernels); batch.eps is then only the config's scalar schedule,
+    which game 0 never had.  The saved artefacts and the progress line are game 0's (trainer.py:79,101-110)."""
+    eps = list(batch.eps)
+    sw = getattr(batch, "sweep", None) or {}
+    if "eps" in sw:
+        col = sw["eps"][:, 0].cpu().numpy()
+        for i in range(min(len(eps), len(col))):
+            eps[i] = float(col[i])
+    return eps
+
+
 def train_one(exp_path, configpath, loadonly=False, print_eps=False):
     if not os.path.exists(exp_path):
         os.mkdir(os.path.join(exp_path))
@@ -145,7 +158,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         if print_freq and not done % print_freq:
             rew = numpy.mean(rewards_log[done - print_freq:done, :], axis=0)
             act = numpy.mean(actions_log[done - print_freq:done, :], axis=0)
-            print(_progress_line(print_eps, batch.eps, time.time() - t, done - 1, rew, act, names))
+            print(_progress_line(print_eps, _eps_of_game0(batch), time.time() - t, done - 1, rew, act, names))
             t = time.time()
 
     # Store result: the reference's artefacts, from game 0
@@ -153,7 +166,7 @@ def train_one(exp_path, configpath, loadonly=False, print_eps=False):
         if isinstance(a, QTable):
             a.table = batch.table(0, i)
             a.counter = batch.counter_of(0, i)
-            a.epsilon = batch.eps[i]
+            a.epsilon = _eps_of_game0(batch)[i]
         else:
             a.set_flat_params(batch.nn[i].params[0].cpu().numpy())
         a.save(os.path.join(exp_path, str(i)))
