@@ -20,13 +20,19 @@ Multi-GPU: games are seed-sharded (game_offset = rank * games), no data-path
 collective; a gloo group provides only the barrier and the max-over-ranks clock.
 
 Prints ONE JSON line (rank 0).  Blocks besides the driver contract's fields:
-  roofline      bound "hbm" by the contract formula: achieved = 368 B x env-steps per
-                launch / mean launch time (HIP events on the launch stream); traffic = HBM bytes per
-                launch from the PMC passes in profiles/traffic.json (a per-game + per-episode model
-                fitted to two launch sizes, so it is defined for any chunk); `issue` = the kernel's
-                REAL bound -- instruction-issue / wait shares from the SQ counters in profiles/
+  roofline      the kernel's BINDING bound (round-3: vector-instruction issue), frac <= 1, recomputable from
+                profiles/: achieved = SQ_INSTS_VALU per launch (profiles/traffic.json: instructions per env-step from
+                the committed PMC summary x the env-steps of this launch) / live launch time (HIP events on the launch
+                stream); peak = 1,024 SIMDs x shader clock / measured issue cost of this kernel's instruction mix
+                (profiles/r03_ubench_issue.md priced over profiles/isa_mix.json).  Beside it: `algorithmic_equiv_gbps`
+                (the contract's 368 B per env-step / launch time: above the 8 TB/s peak because tables stay in LDS for
+                a launch, so it carries no frac), `traffic` (HBM bytes per launch, PMC model) and `measured_hbm_frac`.
+                `stale` is true when the loaded library is not the binary the counters were collected on.
   cpu_baseline  the C oracle (kind "port") on the host cores, bounded sample, + CPU model, core
                 counts and the port/reference ratio measured in the build container
+  secondary     BASELINE configs[3] witnessed by the same run: 2 x Reinforce and QTable vs Reinforce x 65,536 games
+                (full sub-lines with their own roofline / cpu_baseline); --no-secondary skips them
+  library       which libthrl_hip.so ran (path, source hashes, ablation mask); an ablation build is refused
 """
 import argparse
 import json
@@ -46,6 +52,31 @@ ALGO_BYTES_PER_ENV_STEP = 368.0     # 2 agents x (2 x 21
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector
 NN_HIDDEN = 256
+N_SIMD, N_CU = 1024, 256            # MI355X: 256 CUs x 4 SIMD-32
+KEY_WAVE = "k_wave_episodes<float,2,1> (headline)"
+KEY_MIXED = {"rr": "k_mixed_wave<float,NR=2,24,2,memo> (2 x Reinforce)", "qr": "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)"}
+
+
+def library_info():
+    """Which binary runs (thrl_build_info): an ablation build (phases compiled out, results wrong by construction)
+    must never produce a reported number."""
+    from th_rl_amd import _lib
+    info = _lib.build_info()
+    if info["ablate"] != 0:
+        print("bench.py: %s is a TIMING-ONLY ablation build (THRL_ABLATE mask %d): refusing to report numbers from it"
+              % (info["path"], info["ablate"]), file=sys.stderr)
+        sys.exit(2)
+    return info
+
+
+def issue_price(kernel_key):
+    """(price, lo, hi, hash) of one vector instruction of `kernel_key` in SIMD cycles: the measured saturated issue costs
+    (profiles/r03_ubench_issue.md) over the kernel's static instruction-class mix (profiles/isa_mix.json)."""
+    mix = _load_json("isa_mix.json")
+    if not mix or kernel_key not in mix.get("kernels", {}):
+        return None
+    lo, hi = mix["valu_cycles_per_inst_bounds"]
+    return mix["kernels"][kernel_key]["valu_cycles_per_inst_static_mix"], lo, hi, mix
 
 
 def _load_json(name):
@@ -171,64 +202,89 @@ def cpu_baseline_nn(kind, seconds_target=10.0):
                        % (steps, sum(st), wall), **cpu_info())
 
 
-def bench_nn(args):
-    """BASELINE configs[3]: 2 Reinforce agents (agents.py:119-220) x 65,536 games through
-    mixed.MixedGameBatch (--nn-loop fused: thrl_mixed_episodes + the batched update kernels;
-    unfused: one launch per reference call).  --nn-agents qr = the reference's shipped pairing,
-    QTable vs Reinforce.  steps = episodes; the policy trains every 10 episodes."""
-    cpu = None if args.no_cpu_baseline else cpu_baseline_nn(args.nn_agents, args.cpu_seconds)
+def nn_roofline(agents, env_steps, gpu_s, lib):
+    """Roofline block of a neural line: the whole step (episode kernel + update kernels) against vector-instruction issue
+    and against HBM, from profiles/nn_traffic.json (executed VALU instructions and HBM bytes per env-step of each kernel,
+    rocprofv3 --pmc on this shape) x the env-steps of this run / the live GPU time of the timed region.  Executed work
+    only: the policy memo and the state folding SKIP work, and skipped work is not counted."""
+    nt = (_load_json("nn_traffic.json") or {}).get("pairings", {}).get(agents)
+    pr = issue_price(KEY_MIXED.get(agents, ""))
+    out = {"bound": "valu_issue", "kernel": "k_mixed_wave + k_nn_reinforce_train (whole step)", "unit": "Ginst/s",
+           "achieved": None, "peak": None, "frac": None, "traffic": None, "gpu_time_ms": gpu_s * 1e3}
+    if not nt or not pr:
+        out["note"] = "no PMC summary for this pairing in profiles/nn_traffic.json: only the time is measured here"
+        return out
+    price, lo, hi, mix = pr
+    clock = nt["clock_ghz"]
+    simd_cycles = N_SIMD * gpu_s * clock * 1e9
+    valu = sum(k["valu_insts_per_env_step"] * (issue_price(k["isa_key"]) or pr)[0] for k in nt["kernels"].values()) * env_steps
+    insts = sum(k["valu_insts_per_env_step"] for k in nt["kernels"].values()) * env_steps
+    hbm = sum(k["hbm_bytes_per_env_step"] for k in nt["kernels"].values()) * env_steps
+    mean_price = valu / insts
+    out.update(achieved=insts / gpu_s / 1e9, peak=N_SIMD * clock / mean_price, frac=valu / simd_cycles,
+               frac_bounds=[insts * lo / simd_cycles, insts * hi / simd_cycles],
+               traffic=hbm, measured_hbm_gbps=hbm / gpu_s / 1e9, measured_hbm_frac=hbm / gpu_s / 1e9 / HBM_PEAK_GBS,
+               kernels={n: {"time_share_profiled": k["time_share"], "valu_insts_per_env_step": k["valu_insts_per_env_step"],
+                            "hbm_bytes_per_env_step": k["hbm_bytes_per_env_step"], "wait_frac": k.get("wait_frac")}
+                        for n, k in nt["kernels"].items()},
+               inputs={"clock_ghz": clock, "valu_cycles_per_inst": mean_price, "source": nt.get("source"),
+                       "counters_collected_on": nt.get("nn"), "library": lib.get("nn")},
+               stale=bool(nt.get("nn") != lib.get("nn") or mix.get("nn") != lib.get("nn")))
+    return out
+
+
+def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=None):
+    """BASELINE configs[3]: neural-policy agents (agents.py:119-220) x 65,536 games through mixed.MixedGameBatch
+    (fused: thrl_mixed_episodes + the batched update kernels; unfused: one launch per reference call).
+    agents: rr = 2 x Reinforce, qr = the reference's shipped pairing QTable vs Reinforce, qa / qc = QTable vs
+    ActorCritic / CAC, qq = 2 x QTable on the mixed kernel.  steps = episodes; the policy trains every 10 episodes.
+    Returns the JSON line as a dict."""
+    cpu = cpu_baseline_nn(agents, cpu_seconds) if cpu_seconds > 0 else None
     import torch
     from th_rl_amd.mixed import MixedGameBatch
-    G = args.games if args.games != (1 << 20) else 65536
+    lib = lib or library_info()
+    G = games
     ag = {"name": "Reinforce", "gamma": 0.995, "actions": 21, "states": 1, "action_range": [0.2, 0.4]}
-    first = dict(ag) if args.nn_agents == "rr" else dict(CFG["agents"][0])
+    first = dict(ag) if agents == "rr" else dict(CFG["agents"][0])
     second = {"qq": dict(CFG["agents"][1]), "qa": dict(ag, name="ActorCritic", gamma=0.98),
-              "qc": {"name": "CAC", "gamma": 0.98, "states": 1, "action_range": [0.2, 0.4]}}.get(args.nn_agents, dict(ag))
-    config = {"agents": [first, second], "environment": dict(CFG["environment"])}
-    fused = args.nn_loop == "fused"
+              "qc": {"name": "CAC", "gamma": 0.98, "states": 1, "action_range": [0.2, 0.4]}}.get(agents, dict(ag))
+    config = {"agents": [first, second], "environment": dict(CFG["environment"], noise_prob=0)}
+    fused = nn_loop == "fused"
     mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=0).init_tables()
-    mb.run(args.warmup, fused=fused, per_game_logs=False) if fused else mb.run(args.warmup, fused=False)
+    mb.run(warmup, fused=fused, per_game_logs=False) if fused else mb.run(warmup, fused=False)
     torch.cuda.synchronize()
     upd0 = {i: rb.step for i, rb in mb.nn.items()}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    mb.run(args.steps, fused=fused, per_game_logs=False) if fused else mb.run(args.steps, fused=False)
+    mb.run(steps, fused=fused, per_game_logs=False) if fused else mb.run(steps, fused=False)
     ev1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     who = {"qr": "QTable vs Reinforce", "rr": "2-agent Reinforce", "qq": "2-agent QTable (mixed kernel)",
-           "qa": "QTable vs ActorCritic", "qc": "QTable vs CAC"}[args.nn_agents]
-    n_nets = sum(1 for k in mb.kinds if k in ("Reinforce", "ActorCritic"))
+           "qa": "QTable vs ActorCritic", "qc": "QTable vs CAC"}[agents]
     updates = sum(rb.step - upd0[i] for i, rb in mb.nn.items())
-    env_steps = float(G) * T_STEPS * args.steps
-    # Algorithmic work of the neural part (discrete policies 1 -> 256 -> 21, MFMA off): one policy
-    # evaluation per network per env-step = 256 + 256*21 FMAs; one update per network = forward + backward
-    # (3 x the forward FMAs) over the 1,000 replayed transitions, plus the parameter / Adam-state traffic.
-    fwd_fma = NN_HIDDEN + NN_HIDDEN * 21
-    n_tr = 1000
-    flops = 2.0 * fwd_fma * (n_nets * env_steps + 3.0 * n_tr * updates * G)
-    params = 2 * NN_HIDDEN + 21 * NN_HIDDEN + 21
-    upd_bytes = float(updates) * G * params * 4 * 6          # params + Adam m, v: read and written once per update
+    env_steps = float(G) * T_STEPS * steps
     gpu_s = ev0.elapsed_time(ev1) * 1e-3
     out = {"metric": "env-steps/sec, %s (neural policy) x %d games" % (who, G),
-           "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": steps,
+           "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-           "config": {"workload": "%s x %d games, %s loop, MFMA off" % (who, G, args.nn_loop),
+           "config": {"workload": "%s x %d games, %s loop, MFMA off" % (who, G, nn_loop),
                       "network_updates": updates},
-           "roofline": {"bound": "valu_f32", "kernel": "k_mixed_wave + k_nn_*_train (whole step)",
-                        "achieved": flops / gpu_s / 1e12, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / gpu_s / 1e12 / VALU_F32_PEAK_TFLOPS, "traffic": upd_bytes / max(updates, 1) if updates else None,
-                        "algorithmic_flops": flops, "update_bytes_per_launch_algorithmic": upd_bytes / max(updates, 1),
-                        "gpu_time_ms": gpu_s * 1e3,
-                        "note": "algorithmic FLOPs (every step evaluates the policy, every update runs forward + "
-                                "backward over all 1,000 transitions) / GPU time of the timed region (HIP events); "
-                                "the kernels skip work the count includes (policy memo, state folding), so this is a "
-                                "rate of useful work, not of executed FLOPs; `traffic` is the algorithmic parameter + "
-                                "Adam-state bytes of one update launch (not a PMC reading; PMC: profiles/)"}}
+           "roofline": nn_roofline(agents, env_steps, gpu_s, lib)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    del mb
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_nn(args):
+    lib = library_info()
+    G = args.games if args.games != (1 << 20) else 65536
+    out = run_nn(args.nn_agents, G, args.steps, args.warmup, args.nn_loop, 0.0 if args.no_cpu_baseline else args.cpu_seconds, lib)
+    out["library"] = lib
     print(json.dumps(out))
 
 
@@ -299,6 +355,8 @@ def main():
     ap.add_argument("--allow-oversubscribe", action="store_true",
                     help="rehearsal only: let --gpus N run on fewer than N GPUs (ranks share devices; the line is "
                          "flagged `oversubscribed`)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary lines (2 x Reinforce and QTable vs Reinforce x 65,536 games = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true",
                     help="diagnostic only: run without QTable.counter (NOT the reported workload)")
@@ -342,6 +400,7 @@ def main():
     import torch
     import torch.distributed as dist
     from th_rl_amd.batched import GameBatch
+    lib = library_info()
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -439,21 +498,47 @@ def main():
         e_launch = full[0][1]
         algo_bytes_launch = ALGO_BYTES_PER_ENV_STEP * G * T_run * e_launch
         achieved = algo_bytes_launch / avg_launch_s / 1e9
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950
-        # corrections: profiles/summarize.py): bytes = G * (per_game + per_game_episode * E)
-        traffic, issue = None, None
+        # ---- roofline of the dominant kernel: the binding bound is vector-instruction issue.
+        # instructions per env-step: committed PMC summary (profiles/traffic.json <- profiles/r03c25_pmc_summary.csv);
+        # issue cost per instruction: the microbenchmark priced over the kernel's instruction mix; launch time: live.
         tj = _load_json("traffic.json")
         default_cfg = (args.noise_prob in (None, 0.0) and args.epsilon is None and not args.no_counters
                        and args.dtype == "float32" and args.max_steps is None and args.capacity is None
                        and args.pretrain == 0)
-        if tj and tj.get("kernel") == gb.last_kernel and default_cfg and "model" in tj:
+        env_launch = float(G) * T_run * e_launch
+        roof = {"bound": "valu_issue", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
+                "achieved": None, "peak": None, "unit": "Ginst/s", "frac": None, "traffic": None,
+                "avg_launch_ms": avg_launch_s * 1e3, "median_launch_ms": times[len(times) // 2] * 1e3, "launches_timed": len(full),
+                # the contract formula of SURVEY 8(d): 368 algorithmic bytes per env-step / launch time.  Tables stay in LDS
+                # for a whole launch, so this exceeds the HBM peak: a reuse figure, not a fraction of a limit
+                "algorithmic_bytes_per_launch": algo_bytes_launch, "algorithmic_equiv_gbps": achieved,
+                "algorithmic_reuse_vs_hbm_peak": achieved / HBM_PEAK_GBS}
+        pr = issue_price(KEY_WAVE)
+        if tj and tj.get("kernel") == gb.last_kernel and default_cfg and "model" in tj and pr and gb.last_kernel == "wave":
+            price, p_lo, p_hi, mix = pr
+            iss = tj["issue"]
+            ipe, clock = iss["insts_per_env_step"], iss["clock_ghz"]
+            simd_cycles = N_SIMD * avg_launch_s * clock * 1e9
+            valu = ipe["valu"] * env_launch
             m = tj["model"]
             traffic = float(G) * (m["bytes_per_game_per_launch"] + m["bytes_per_game_per_episode"] * e_launch)
-            issue = dict(tj.get("issue") or {})
-            sc = issue.pop("occupancy_scaling", None)           # keep the line compact: only the fitted share
-            if sc:
-                issue["latency_share_at_20_waves"] = sc.get("latency_share_at_20_waves")
-            issue = issue or None
+            sc = iss.get("occupancy_scaling") or {}
+            roof.update(
+                achieved=valu / avg_launch_s / 1e9, peak=N_SIMD * clock / price, frac=valu * price / simd_cycles,
+                # the same with every vector instruction at the fast (all-VGPR two-source) / the slow price
+                frac_bounds=[valu * p_lo / simd_cycles, valu * p_hi / simd_cycles],
+                traffic=traffic, measured_hbm_gbps=traffic / avg_launch_s / 1e9,
+                measured_hbm_frac=traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                # the other units, same pricing (scalar unit: one instruction per cycle per CU; LDS: 128 B/clk/CU)
+                salu_frac=ipe["salu"] * env_launch * mix["price_cycles"]["salu"] / simd_cycles,
+                lds_frac=ipe["lds"] * env_launch * mix["price_cycles"]["lds_b32"] / simd_cycles,
+                inputs={"valu_insts_per_env_step": ipe["valu"], "salu": ipe["salu"], "lds": ipe["lds"], "branch": ipe["branch"],
+                        "valu_cycles_per_inst": price, "price_bounds": [p_lo, p_hi], "clock_ghz": clock, "simds": N_SIMD,
+                        "source": [iss.get("source"), "profiles/r03_ubench_issue.md", "profiles/isa_mix.json"],
+                        "counters_collected_on": tj.get("wave"), "library": lib.get("wave")},
+                wave_time={"issuing": iss.get("issue_frac"), "parked_on_waitcnt": iss.get("wait_frac"), "stalled_at_issue": iss.get("stall_frac"),
+                           "latency_share_at_20_waves": sc.get("latency_share_at_20_waves")},
+                stale=bool(tj.get("wave") != lib.get("wave") or mix.get("wave") != lib.get("wave")))
         out = {
             "metric": "env-steps/sec, 2-agent PD x 1M parallel games",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -470,20 +555,8 @@ def main():
                        "counters": not args.no_counters, "epsilon_start": eps_at_start, "pretrain_episodes": args.pretrain,
                        "noise_prob": CFG["environment"]["noise_prob"], "parallelism": "seed-sharded x%d, no collective" % n_gpus,
                        "devices_visible": n_dev, "oversubscribed": world > n_dev},
-            "roofline": {"bound": "hbm", "kernel": "k_wave_episodes" if gb.last_kernel == "wave" else "k_generic_episodes",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         # what the HBM actually moved per second (PMC traffic / launch time): tables stay
-                         # in LDS for a whole launch, so it is far below `achieved` -- the contract fraction
-                         # measures algorithmic work, and exceeds 1 once LDS reuse beats the no-reuse bound
-                         "traffic_gbps": None if traffic is None else traffic / avg_launch_s / 1e9,
-                         "measured_hbm_frac": None if traffic is None else traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
-                         "avg_launch_ms": avg_launch_s * 1e3, "median_launch_ms": times[len(times) // 2] * 1e3,
-                         "launches_timed": len(full),
-                         # the kernel's real bound (SQ counters, profiles/): share of the SIMDs' VALU issue
-                         # cycles used and the split of wave time into issuing / stalled / waiting
-                         "issue": issue},
+            "roofline": roof,
+            "library": lib,
         }
         if world > 1:
             # N = 1-equivalent figures so a SCALE record can be checked against BENCH directly
@@ -491,6 +564,13 @@ def main():
                                "value": [G * T_run * args.steps / s for s in per_rank]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        if world == 1 and default_cfg and not args.no_secondary and args.kernel == "wave" and G == (1 << 20):
+            # BASELINE configs[3] in front of the driver: the neural pairings at 65,536 games, after the headline's
+            # tensors are released (a few seconds each; their own roofline and cpu_baseline)
+            del gb
+            torch.cuda.empty_cache()
+            out["secondary"] = [run_nn(p, 65536, 40, 10, "fused", 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 5.0), lib)
+                                for p in ("rr", "qr")]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

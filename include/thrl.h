@@ -333,7 +333,18 @@ typedef struct {
     const double* sweep_eps_step;
     double*       sweep_eps;             /* in/out: current epsilon per (agent, game)        */
     const double* sweep_noise_prob;
+    /* Optional scratch for the POLICY TABLE (ABI v3): inside one call the networks are frozen and, in a game
+     * whose agents are all discrete, the state after a step is a function of that step's action tuple, so the
+     * kernel evaluates Reinforce.pi / ActorCritic.pi (agents.py:147-152) once per call and tuple and looks the
+     * result up afterwards (identical bits).  Device, thrl_mixed_policy_table_bytes() bytes, contents need not
+     * survive between calls; NULL = evaluate the policy at every step (same results, slower). */
+    float*   policy_tab;
+    size_t   policy_tab_bytes;
 } thrl_mixed;
+/* bytes of thrl_mixed.policy_tab this configuration can use on this many games (0: the table does not apply --
+ * no discrete neural agent, a continuous agent in the game, more than 2,048 action tuples, or a price grid small
+ * enough for the in-LDS memo) */
+size_t thrl_mixed_policy_table_bytes(const thrl_cfg* cfg, const thrl_mixed* mx);
 int thrl_mixed_episodes(const thrl_cfg* cfg, thrl_mixed* mx, void* q, int32_t* counter, double* state,
                         thrl_run* run, double* game_reward_log, double* game_action_log, void* stream);
 

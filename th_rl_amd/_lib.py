@@ -72,6 +72,7 @@ class Mixed(ctypes.Structure):
         ("sweep_gamma", ctypes.c_void_p), ("sweep_alpha", ctypes.c_void_p),
         ("sweep_eps_end", ctypes.c_void_p), ("sweep_eps_step", ctypes.c_void_p),
         ("sweep_eps", ctypes.c_void_p), ("sweep_noise_prob", ctypes.c_void_p),
+        ("policy_tab", ctypes.c_void_p), ("policy_tab_bytes", ctypes.c_size_t),
     ]
 
 
@@ -82,7 +83,7 @@ SYMBOLS = [
     "thrl_qtable_episodes", "thrl_play_greedy", "thrl_op_sample_action", "thrl_op_encode", "thrl_op_scale",
     "thrl_op_env_step", "thrl_op_td_update",
     "thrl_nn_param_count", "thrl_nn_init", "thrl_nn_act", "thrl_nn_reinforce_train", "thrl_op_draws",
-    "thrl_mixed_episodes", "thrl_ac_param_count", "thrl_ac_init", "thrl_ac_act", "thrl_ac_train",
+    "thrl_mixed_episodes", "thrl_mixed_policy_table_bytes", "thrl_ac_param_count", "thrl_ac_init", "thrl_ac_act", "thrl_ac_train",
     "thrl_cac_init", "thrl_cac_act", "thrl_cac_train",
 ]
 CAC_PARAMS = 1283
@@ -176,6 +177,8 @@ def load():
     L.thrl_ac_train.restype = ctypes.c_int
     L.thrl_ac_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp,
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
+    L.thrl_mixed_policy_table_bytes.restype = ctypes.c_size_t
+    L.thrl_mixed_policy_table_bytes.argtypes = [cfgp, ctypes.POINTER(Mixed)]
     L.thrl_mixed_episodes.restype = ctypes.c_int
     L.thrl_mixed_episodes.argtypes = [cfgp, ctypes.POINTER(Mixed), vp, vp, vp, ctypes.POINTER(Run), vp, vp, vp]
     if L.thrl_version() != ABI_VERSION:

@@ -764,6 +764,7 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
         return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it switches the noise draws on)");
     a.sw_gamma = mx->sweep_gamma; a.sw_alpha = mx->sweep_alpha; a.sw_eps_end = mx->sweep_eps_end;
     a.sw_eps_step = mx->sweep_eps_step; a.sw_eps = mx->sweep_eps; a.sw_noise_prob = mx->sweep_noise_prob;
+    a.policy_tab = mx->policy_tab; a.policy_tab_bytes = mx->policy_tab ? mx->policy_tab_bytes : 0;
     const char* why = "";
     if (plan_mixed(a, c->q_dtype, &why)) return fail(THRL_ERR_UNSUPPORTED, "thrl_mixed_episodes: %s", why);
     const int e = launch_mixed(a, c->q_dtype, (hipStream_t)stream);
@@ -784,6 +785,21 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
             }
         }
     return THRL_OK;
+}
+
+size_t thrl_mixed_policy_table_bytes(const thrl_cfg* c, const thrl_mixed* mx) {
+    if (validate(c) != THRL_OK || !mx) return 0;
+    MixedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = c->n_games; a.N = c->n_agents; a.T = c->max_steps;
+    fill_agents(c, a.ag, &a.env);
+    for (int i = 0; i < c->n_agents; i++) {
+        if (mx->kind[i] < 0 || mx->kind[i] > 3) return 0;
+        a.kind[i] = mx->kind[i];
+    }
+    const char* why = "";
+    if (plan_mixed(a, c->q_dtype, &why)) return 0;
+    return a.ptab_tuples > 0 ? a.ptab_need_bytes : 0;
 }
 
 int thrl_cac_init(int n_games, float* params, uint64_t seed, uint64_t game_offset, int agent, void* stream) {

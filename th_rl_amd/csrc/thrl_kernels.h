@@ -162,6 +162,8 @@ struct MixedArgs {
     int32_t lds_off[THRL_MAXA];                                        // QTable: element offset of the table in LDS; CAC: float offset
     int32_t lds_bytes;
     int32_t memo_lds_byte0, memo_on, memo_k;                                   // memoised policy CDFs [n_r][64][APAD] floats
+    float* policy_tab; size_t policy_tab_bytes, ptab_need_bytes;               // HBM policy table [G][n_r][tuples][APAD] (caller's scratch)
+    int32_t ptab_on, ptab_tuples;
     int32_t n_cac, cac_lds_byte0;                                      // CAC networks (kind 3) live in LDS after the tables
     int32_t stage_lds_byte0;                                           // 16 steps of transitions staged before they go to the replay rings
     // per-game sweeps of the QTable agents / the env (null = the scalars above), [N][G] except noise_prob [G]

@@ -36,7 +36,9 @@ template <> __device__ __forceinline__ double neg_inf<double>() { return -(doubl
 // scaled action / reward) and is picked with v_readlane, so the large bodies -- the policy, the
 // TD update -- exist once in the code, not once per agent slot.
 // Draw layout: one Philox batch covers 16 steps x 4 agent pairs, lane = pair * 16 + (step & 15).
-template <typename T, int NR, int APAD, int NA, bool CAC, bool MEMO>
+// MEMO: 0 = every step evaluates the policy; 1 = CDFs memoised in LDS by a tag search (small price grids);
+//       2 = CDFs in a per-game HBM table indexed by the ACTION TUPLE of the previous step (see below).
+template <typename T, int NR, int APAD, int NA, bool CAC, int MEMO>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : (NR == 0 ? 4 : 2))))
 k_mixed_wave(const MixedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_mx[];
@@ -52,6 +54,15 @@ k_mixed_wave(const MixedArgs a) {
     int32_t* const st_act = reinterpret_cast<int32_t*>(st_rew + 16 * a.N);                  // [16][N]
     unsigned tag0 = 0u, tag1 = 0u;
     int nmemo0 = 0, nmemo1 = 0;
+    // MEMO == 2, the policy table: the networks are frozen inside a launch and in a noise-free game the state after a step
+    // is a function of that step's action tuple alone, so the CDF the policy returns for it is computed ONCE per launch
+    // and tuple -- by the same code on the same input, hence the same bits -- and kept in HBM scratch
+    // [G][NR][tuples][APAD] (written and read by this wave only; L2 / MALL resident).  A step then costs one 96-byte load
+    // instead of the ~400-instruction evaluation.  Direct-mapped: the index is known from the previous step's actions, no
+    // search; lane l of `pvalid` holds the valid bits of tuples 32l .. 32l+31.  prev_tuple < 0 (first step of a launch, a
+    // noisy step): the state is off the grid and the policy is evaluated as before.
+    unsigned pvalid0 = 0u, pvalid1 = 0u;
+    int prev_tuple = -1;
     const int g = blockIdx.x, lane = threadIdx.x;
     const int N = a.N, G = a.G, Tn = a.T;
     const uint64_t gid = a.game_offset + (uint64_t)g;
@@ -165,13 +176,29 @@ k_mixed_wave(const MixedArgs a) {
                 int& nmemo = r == 0 ? nmemo0 : nmemo1;
                 const int K = a.memo_k;                                      // entries in use (<= kMemo)
                 float* memo = lds_memo + r * K * APAD;
-                const unsigned long long found = MEMO ? __ballot(tag == key && lane < min(nmemo, K)) : 0ull;
+                const unsigned long long found = MEMO == 1 ? __ballot(tag == key && lane < min(nmemo, K)) : 0ull;
                 float c;
-                if (MEMO && found) {
+                if (MEMO == 2) {
+                    unsigned& pvalid = r == 0 ? pvalid0 : pvalid1;
+                    float* const row = a.policy_tab + (((size_t)g * NR + r) * (size_t)a.ptab_tuples + (size_t)max(prev_tuple, 0)) * APAD;
+                    const bool known = prev_tuple >= 0 && ((lane_u32(pvalid, prev_tuple >> 5) >> (prev_tuple & 31)) & 1u);
+                    if (known) {
+                        // (agent scope: served by the L2, where this wave's own earlier store of the row is)
+                        c = __hip_atomic_load(row + min(lane >> 1, APAD - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        c = policy_cdf(policy_probs(r == 0 ? net0 : net1, A, x, lane));
+                        if (prev_tuple >= 0) {
+                            if (!(lane & 1) && (lane >> 1) < APAD)
+                                __hip_atomic_store(row + (lane >> 1), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == (prev_tuple >> 5)) pvalid |= 1u << (prev_tuple & 31);
+                            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the row is in the L2 before any later read
+                        }
+                    }
+                } else if (MEMO == 1 && found) {
                     c = memo[(int)__builtin_ctzll(found) * APAD + min(lane >> 1, APAD - 1)];
                 } else {
                     c = policy_cdf(policy_probs(r == 0 ? net0 : net1, A, x, lane));
-                    if (MEMO) {
+                    if (MEMO == 1) {
                         const int slot = nmemo >= K ? nmemo - K : nmemo;     // round-robin replacement
                         if (!(lane & 1) && (lane >> 1) < APAD) memo[slot * APAD + (lane >> 1)] = c;
                         if (lane == slot) tag = key;
@@ -198,10 +225,20 @@ k_mixed_wave(const MixedArgs a) {
             }
             // ---- NoisyPriceState.step (environments.py:25-39)
             double a_eff = env_a;
+            bool on_grid = true;
             if (noisy) {
                 const uint32_t nx = lane_u32(xn.x, tl), ny = lane_u32(xn.y, tl);
-                if (u01_32(nx) < noise_prob_g)
+                if (u01_32(nx) < noise_prob_g) {
                     a_eff = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(env_a, a.env.noise_lo), u01_32(ny)));
+                    on_grid = false;
+                }
+            }
+            if (MEMO == 2) {          // the tuple that produces the next state (mixed radix over the agents' action counts)
+                int tup = 0;
+#pragma unroll
+                for (int i = 0; i < NA; i++)
+                    if (i < N) tup = tup * a.ag[i].n_actions + __builtin_amdgcn_readlane(act_l, i);
+                prev_tuple = on_grid ? tup : -1;
             }
             const double A_l = __dmul_rn(env_ratio, scaled_l);
             double Q = 0.0;
@@ -324,7 +361,7 @@ k_mixed_wave(const MixedArgs a) {
     if (a.sw_eps && lane < N && a.kind[lane] == 0) a.sw_eps[(size_t)lane * G + g] = eps_l;
 }
 
-template <typename T, int NR, int APAD, int NA, bool CAC, bool MEMO>
+template <typename T, int NR, int APAD, int NA, bool CAC, int MEMO>
 int launch_cac(const MixedArgs& a, hipStream_t s) {
     auto kern = k_mixed_wave<T, NR, APAD, NA, CAC, MEMO>;
     if (a.lds_bytes > 48 * 1024) {
@@ -339,9 +376,10 @@ int launch_cac(const MixedArgs& a, hipStream_t s) {
 // the CAC code (Box-Muller, LDS-resident heads) is compiled only into the variants that need it
 template <typename T, int NR, int APAD, int NA>
 int launch_one(const MixedArgs& a, hipStream_t s) {
-    if (a.n_cac > 0) return launch_cac<T, NR, APAD, NA, true, false>(a, s);
-    if (NR > 0 && a.memo_on) return launch_cac<T, NR, APAD, NA, false, true>(a, s);
-    return launch_cac<T, NR, APAD, NA, false, false>(a, s);
+    if (a.n_cac > 0) return launch_cac<T, NR, APAD, NA, true, 0>(a, s);
+    if (NR > 0 && a.memo_on) return launch_cac<T, NR, APAD, NA, false, 1>(a, s);
+    if (NR > 0 && a.ptab_on) return launch_cac<T, NR, APAD, NA, false, 2>(a, s);
+    return launch_cac<T, NR, APAD, NA, false, 0>(a, s);
 }
 
 template <typename T, int NA>
@@ -427,6 +465,22 @@ int plan_mixed(MixedArgs& a, int q_dtype, const char** why) {
         }
     }
     if (a.lds_bytes > 64 * 1024) { *why = "tables and CAC networks of one game exceed 64 KiB of LDS"; return -1; }
+    // Policy table in HBM (MEMO == 2) where the LDS memo does not apply: every agent discrete, at most 2,048 action tuples
+    // (64 lanes x 32 valid bits); the caller provides the scratch (thrl_mixed.policy_tab), without it the policy is
+    // evaluated every step as before.
+    a.ptab_on = 0; a.ptab_tuples = 0;
+    if (a.n_r > 0 && a.n_cac == 0 && !a.memo_on) {
+        long combos = 1;
+        for (int i = 0; i < a.N && combos <= 2048; i++) combos *= a.ag[i].n_actions;
+        if (combos <= 2048) {
+            a.ptab_tuples = (int)combos;
+            int amax = 0;
+            for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ragent[r]].n_actions > amax ? a.ag[a.ragent[r]].n_actions : amax;
+            const size_t need = (size_t)a.G * a.n_r * (size_t)combos * (amax <= 24 ? 24 : 32) * sizeof(float);
+            a.ptab_need_bytes = need;
+            if (a.policy_tab && a.policy_tab_bytes >= need) a.ptab_on = 1;
+        }
+    }
     return 0;
 }
 

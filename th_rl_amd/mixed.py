@@ -102,6 +102,8 @@ class MixedGameBatch:
                 raise ThrlError("%s agent %d would train on %d transitions per update (min_memory=%d, max_steps=%d); "
                                 "the device update kernel takes at most %d" % (self.kinds[i], i, n_train,
                                                                                 self.min_memory[i], self.T, limit))
+        self.policy_table = True             # False: the fused kernel evaluates the policy at every step (same results)
+        self._ptab = None
         self.count = [0] * self.N            # appends since the last empty()
         self.episode = 0
         self.initialized = False
@@ -367,6 +369,13 @@ class MixedGameBatch:
                 for key in ("gamma", "alpha", "eps_end", "eps_step", "eps", "noise_prob"):
                     if key in self.sweep:
                         setattr(mx, "sweep_" + key, self.sweep[key].data_ptr())
+                if self.policy_table:
+                    # scratch of the kernel's policy table (include/thrl.h): allocated once, contents per launch
+                    if self._ptab is None:
+                        need = int(self.L.thrl_mixed_policy_table_bytes(ctypes.byref(self.cfg), ctypes.byref(mx)))
+                        self._ptab = torch.empty((max(need, 4) // 4,), dtype=torch.float32, device=self.device) if need else False
+                    if self._ptab is not False:
+                        mx.policy_tab, mx.policy_tab_bytes = self._ptab.data_ptr(), self._ptab.numel() * 4
                 r = _lib.Run()
                 r.seed, r.game_offset, r.first_episode, r.n_episodes = self.seed, self.game_offset, self.episode, k
                 for i in range(N):
