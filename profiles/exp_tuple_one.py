@@ -1,0 +1,26 @@
+"""One configuration of the tuple-chain kernel for rocprofv3 passes: python profiles/exp_tuple_one.py [three|two] [games]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from th_rl_amd.batched import GameBatch
+AG = dict(name="QTable", gamma=0.95, actions=21, states=100, alpha=0.1, eps_end=0.001, epsilon=0.5, eps_step=0.9995, action_range=[0.2, 0.4])
+ENV = dict(name="NoisyPriceState", noise_prob=0, a=10, b=1, nplayers=2, max_steps=100)
+CFGS = {"three": {"agents": [dict(AG, actions=11, states=50, action_range=[0.1, 0.3], min_memory=25),
+                             dict(AG, actions=21, states=100, action_range=[0.15, 0.35], min_memory=25),
+                             dict(AG, actions=5, states=20, action_range=[0.0, 0.3], min_memory=25, max_state=10)],
+                  "environment": dict(ENV, nplayers=3, max_steps=25)},
+        "two": {"agents": [dict(AG, actions=15, min_memory=100), dict(AG, actions=21, action_range=[0.15, 0.45])], "environment": dict(ENV)}}
+name = sys.argv[1] if len(sys.argv) > 1 else "three"
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+kern = sys.argv[3] if len(sys.argv) > 3 else "tuple"
+cfg = CFGS[name]
+gb = GameBatch(cfg, n_games=G, dtype="float32", kernel=kern, seed=0).init_tables()
+E = 32
+gb.run(E, sync=False); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    gb.run(E, sync=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+T = cfg["environment"]["max_steps"]
+print("%s G=%d %s %.3e env-steps/s (%.2f ms per %d episodes)" % (name, G, gb.last_kernel, G * T * E / dt, dt * 1e3, E))

@@ -8,8 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THRL_LIB") or os.path.join(HERE, "libthrl_hip.so")
 MAXA = 8
 
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE_PLAIN, KERNEL_WAVE_GREEDY = 0, 1, 2, 3, 4
-KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wave"}
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE_PLAIN, KERNEL_WAVE_GREEDY, KERNEL_TUPLE = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = {0: "auto", 1: "generic", 2: "wave", 5: "tuple"}
 ABI_VERSION = 3
 
 

@@ -17,7 +17,7 @@ from ._lib import ThrlError
 
 _KERNELS = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "wave": _lib.KERNEL_WAVE,
             # the wave kernel with its code variant pinned (same results; include/thrl.h)
-            "wave_plain": _lib.KERNEL_WAVE_PLAIN, "wave_greedy": _lib.KERNEL_WAVE_GREEDY}
+            "wave_plain": _lib.KERNEL_WAVE_PLAIN, "wave_greedy": _lib.KERNEL_WAVE_GREEDY, "tuple": _lib.KERNEL_TUPLE}
 _WAVE_IDS = (_lib.KERNEL_WAVE, _lib.KERNEL_WAVE_PLAIN, _lib.KERNEL_WAVE_GREEDY)
 
 

@@ -254,6 +254,97 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- the tuple-chain kernel (thrl_tuple_kernel.h): 1-4 QTable agents with individual grids, state = action tuple
+struct TuplePlan {
+    bool ok;
+    char why[200];
+    TupleArgs a;                    // geometry fields filled: tuples, windows, LDS layout, LUT offsets
+    int waves_per_block, blocks_per_cu;
+    size_t lut_image_bytes;
+};
+constexpr size_t kTupleWsBytes = 160 * 1024;       // LUT image (< 128 KiB) + the launch's work counter in the last 64 bytes
+
+TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
+    TuplePlan p;
+    memset(&p, 0, sizeof(p));
+#define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
+    const int N = c->n_agents, T = c->max_steps;
+    if (N < 1 || N > kTupMaxN) NO("more than 4 agents");
+    if (c->noise_prob > 0.0) NO("environment noise (the state must be a function of the action tuple)");
+    if (T > 256) NO("more than 256 steps per episode");
+    long tuples = 1;
+    for (int i = 0; i < N; i++) {
+        if (c->n_actions[i] > 64) NO("more than 64 actions");
+        tuples *= c->n_actions[i];
+        if (tuples > kTupMaxTuples) NO("more than 4,096 action tuples");
+        // train_net must train -- and empty the buffer -- after every episode, on exactly that episode's transitions
+        // (buffers.py:12-19, agents.py:60,77): min_memory <= T <= capacity
+        if (!(c->min_memory[i] <= T && T <= c->capacity[i])) NO("replay buffer does not fill / train once per episode");
+        if (run && run->mem_count[i] != 0) NO("non-empty replay memory on entry");
+    }
+    TupleArgs& a = p.a;
+    a.N = N; a.T = T; a.tuples = (int)tuples;
+    // row windows: both encodes of the price of every tuple
+    int lo[kTupMaxN], hi[kTupMaxN];
+    for (int i = 0; i < N; i++) { lo[i] = 1 << 30; hi[i] = -1; }
+    const double ratio = c->env_a / c->env_b;
+    int digit[kTupMaxN] = {0, 0, 0, 0};
+    for (long t = 0; t < tuples; t++) {
+        double Q = 0.0;
+        for (int i = 0; i < N; i++) Q = Q + ratio * h_scale(digit[i], c, i);
+        double price = c->env_a - c->env_b * Q;
+        if (!(price > 0.0)) price = 0.0;
+        for (int i = 0; i < N; i++) {
+            const int r64 = h_encode64(price, c, i), r32 = h_encode32(price, c, i);
+            if (r64 < 0 || r64 > c->n_states[i] || r32 < 0 || r32 > c->n_states[i]) NO("price outside a table on the action grid");
+            lo[i] = r64 < lo[i] ? r64 : lo[i]; lo[i] = r32 < lo[i] ? r32 : lo[i];
+            hi[i] = r64 > hi[i] ? r64 : hi[i]; hi[i] = r32 > hi[i] ? r32 : hi[i];
+        }
+        for (int i = N - 1; i >= 0; i--) { if (++digit[i] < c->n_actions[i]) break; digit[i] = 0; }     // last agent = fastest digit
+    }
+    const int esz = c->q_dtype == 1 ? 8 : 4;
+    int elems = 0, am = 0, hd = 0;
+    for (int i = 0; i < N; i++) {
+        a.row_lo[i] = lo[i]; a.win_rows[i] = hi[i] - lo[i] + 1;
+        if (a.win_rows[i] + 2 > 256) NO("reachable row window > 254 rows");
+        const int cells = (a.win_rows[i] + 2) * c->n_actions[i];
+        if (cells > 65535) NO("more than 65,535 resident table cells per agent");
+        a.tab_off[i] = elems; elems += (cells + 3) & ~3;
+        a.am_off_i[i] = am; am += (a.win_rows[i] + 2 + 3) & ~3;
+        a.hist_off_i[i] = hd; hd += (cells + 1) / 2;
+    }
+    a.am_off = (int)align_up((size_t)elems * esz, 16);
+    a.g_off = (int)align_up((size_t)a.am_off + am, 16);
+    a.hist_off = (int)align_up((size_t)a.g_off + 4 * ((size_t)tuples + 1), 16);
+    a.hist_dwords = hd;
+    a.game_lds_bytes = (int)align_up((size_t)a.hist_off + 4 * (size_t)hd, 16);
+    a.aq_off = (int)align_up((size_t)tuples * N * 2, 16);
+    a.lut_lds_bytes = a.aq_off + N * 64 * 8 * 2;
+    a.price_off = a.lut_lds_bytes;
+    p.lut_image_bytes = (size_t)a.price_off + 8 * (size_t)tuples;
+    if (p.lut_image_bytes > kTupleWsBytes - 64) NO("LUT image too large");
+    const DevInfo dv = dev_info();
+    int cap_waves = dv.waves_per_cu < 16 ? dv.waves_per_cu : 16;         // the kernel is compiled for 4 waves per SIMD
+    int best_w = 0, best_total = 0, best_b = 0;
+    for (int w = 1; w <= 16; w++) {
+        const int lds = a.lut_lds_bytes + w * a.game_lds_bytes;
+        if (lds > dv.lds_per_cu) break;
+        int b = dv.lds_per_cu / (((lds + 511) / 512) * 512);
+        if (b * w > cap_waves) b = cap_waves / w;
+        if (b < 1) continue;
+        const int total = b * w;
+        const bool even = (w & 3) == 0, best_even = best_w > 0 && (best_w & 3) == 0;
+        if (total > best_total || (total == best_total && ((even && !best_even) || (even == best_even && w < best_w)))) {
+            best_total = total; best_w = w; best_b = b;
+        }
+    }
+    if (best_w == 0) NO("tables of one game do not fit LDS");
+    p.waves_per_block = best_w; p.blocks_per_cu = best_b;
+    p.ok = true;
+    return p;
+#undef NO
+}
+
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
 
 // Workspace of the wave kernel, sized from the config and the current device:
@@ -323,13 +414,18 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
 size_t thrl_workspace_bytes(const thrl_cfg* c) {
     if (validate(c) != THRL_OK) return 0;
     const WavePlan p = plan_wave(c, nullptr, false);
-    if (!p.ok) return kLutRegion;                  // the generic kernel keeps nothing there
+    if (!p.ok) return plan_tuple(c, nullptr).ok ? kTupleWsBytes : kLutRegion;      // (the generic kernel keeps nothing there)
     return wave_workspace(c, p).bytes;
 }
 int thrl_select_kernel(const thrl_cfg* c, int injected) {
     if (validate(c) != THRL_OK) return THRL_ERR_BAD_CONFIG;
     const WavePlan p = plan_wave(c, nullptr, injected != 0);
-    if (!p.ok) { snprintf(g_err, sizeof(g_err), "generic kernel: %s", p.why); return THRL_KERNEL_GENERIC; }
+    if (!p.ok) {
+        const TuplePlan tp = plan_tuple(c, nullptr);
+        if (tp.ok) return THRL_KERNEL_TUPLE;
+        snprintf(g_err, sizeof(g_err), "generic kernel: %s; %s", p.why, tp.why);
+        return THRL_KERNEL_GENERIC;
+    }
     return THRL_KERNEL_WAVE;
 }
 
@@ -512,6 +608,68 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
     return THRL_OK;
 }
 
+static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, TuplePlan& p, hipStream_t s) {
+    if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
+    if (!b->workspace || b->workspace_bytes < kTupleWsBytes)
+        return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes, kTupleWsBytes);
+    if ((b->reward_log == nullptr) != (b->action_log == nullptr))
+        return fail(THRL_ERR_NULL, "reward_log and action_log must both be given or both NULL");
+    TupleArgs& a = p.a;
+    a.G = c->n_games;
+    a.stride = (int64_t)thrl_table_stride(c);
+    AgentParams ag[THRL_MAXA];
+    fill_agents(c, ag, &a.env);
+    for (int i = 0; i < a.N; i++) a.ag[i] = ag[i];
+    a.q = b->q; a.counter = b->counter; a.state = b->state;
+    unsigned char* lut = (unsigned char*)b->workspace;
+    a.lut = lut;
+    a.next_game = (int32_t*)((char*)b->workspace + kTupleWsBytes - 64);
+    a.seed = run->seed; a.game_offset = run->game_offset;
+    a.waves_per_block = p.waves_per_block;
+    int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
+    const int max_grid = dev_info().cus * p.blocks_per_cu;
+    if (grid > max_grid) grid = max_grid;
+    a.total_waves = grid * p.waves_per_block;
+    const int block = p.waves_per_block * 64;
+    const size_t lds = (size_t)a.lut_lds_bytes + (size_t)p.waves_per_block * a.game_lds_bytes;
+    int e = launch_tuple_lut(a, lut, s);
+    if (e) return hip_fail(e, "k_tuple_lut launch");
+    const int nlog = run->n_episodes * c->n_agents;
+    if (b->reward_log) {
+        hipError_t e1 = hipMemsetAsync(b->reward_log, 0, sizeof(double) * nlog, s);
+        hipError_t e2 = hipMemsetAsync(b->action_log, 0, sizeof(double) * nlog, s);
+        if (e1 != hipSuccess || e2 != hipSuccess) return hip_fail(e1 != hipSuccess ? e1 : e2, "log memset");
+    }
+    int done = 0;
+    while (done < run->n_episodes) {
+        const int n = run->n_episodes - done < kTupMaxEpisodes ? run->n_episodes - done : kTupMaxEpisodes;
+        a.n_episodes = n;
+        a.first_episode = run->first_episode + (uint64_t)done;
+        a.sum_reward = b->reward_log ? b->reward_log + (size_t)done * a.N : nullptr;
+        a.sum_action = b->action_log ? b->action_log + (size_t)done * a.N : nullptr;
+        if (b->inj_u) {
+            const size_t per_ep = (size_t)c->max_steps * a.N * (size_t)c->n_games;
+            a.inj_u = b->inj_u + (size_t)done * per_ep;
+            a.inj_choice = b->inj_choice + (size_t)done * per_ep;
+        }
+        for (int ep = 0; ep < n; ep++)
+            for (int i = 0; i < a.N; i++) {
+                a.eps[ep][i] = run->eps[i];
+                run->eps[i] = c->eps_end[i] + (run->eps[i] - c->eps_end[i]) * c->eps_step[i];       // agents.py:78
+            }
+        if (hipMemsetAsync(a.next_game, 0, sizeof(int32_t), s) != hipSuccess) return hip_fail((int)hipGetLastError(), "hipMemsetAsync");
+        e = launch_tuple(a, c->q_dtype, grid, block, lds, s);
+        if (e) return hip_fail(e, "k_tuple_episodes launch");
+        done += n;
+    }
+    if (b->reward_log) {
+        e = launch_finalize_logs(b->reward_log, b->action_log, nlog, c->n_games, s);
+        if (e) return hip_fail(e, "k_finalize_logs launch");
+    }
+    run->kernel_used = THRL_KERNEL_TUPLE;
+    return THRL_OK;
+}
+
 int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, void* stream) {
     int rc = validate(c);
     if (rc) return rc;
@@ -524,8 +682,20 @@ int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run
     const bool per_game_logs = b->game_reward_log || b->game_action_log;
     int k = run->kernel;
     if (k != THRL_KERNEL_AUTO && k != THRL_KERNEL_GENERIC && k != THRL_KERNEL_WAVE && k != THRL_KERNEL_WAVE_PLAIN &&
-        k != THRL_KERNEL_WAVE_GREEDY)
+        k != THRL_KERNEL_WAVE_GREEDY && k != THRL_KERNEL_TUPLE)
         return fail(THRL_ERR_BAD_CONFIG, "unknown kernel id %d", k);
+    const bool any_sweep = b->sweep_gamma || b->sweep_alpha || b->sweep_eps_end || b->sweep_eps_step || b->sweep_eps || b->sweep_noise_prob;
+    if (k == THRL_KERNEL_TUPLE || k == THRL_KERNEL_AUTO) {
+        // (AUTO prefers the two-agent wave kernel where it applies: decided below; the tuple kernel takes what that one cannot)
+        TuplePlan tp = plan_tuple(c, run);
+        if (tp.ok && per_game_logs) { tp.ok = false; snprintf(tp.why, sizeof(tp.why), "per-game logs requested"); }
+        if (tp.ok && any_sweep) { tp.ok = false; snprintf(tp.why, sizeof(tp.why), "per-game sweeps"); }
+        if (k == THRL_KERNEL_TUPLE) {
+            if (!tp.ok) return fail(THRL_ERR_UNSUPPORTED, "tuple kernel cannot run this config: %s", tp.why);
+            return run_tuple(c, b, run, tp, (hipStream_t)stream);
+        }
+        if (tp.ok && !plan_wave(c, run, injected).ok) return run_tuple(c, b, run, tp, (hipStream_t)stream);
+    }
     const int force_variant = k == THRL_KERNEL_WAVE_PLAIN ? 1 : (k == THRL_KERNEL_WAVE_GREEDY ? 2 : 0);
     if (force_variant) k = THRL_KERNEL_WAVE;
     if (k != THRL_KERNEL_GENERIC) {

@@ -79,6 +79,37 @@ struct WaveArgs {
     double eps[kWaveMaxEpisodes][2];
 };
 
+// ---- fused kernel for 1-4 QTable agents with individual grids (thrl_tuple_kernel.h): state = action tuple
+constexpr int kTupMaxN = 4;
+constexpr int kTupMaxEpisodes = 32;
+constexpr int kTupMaxTuples = 4096;
+struct TupleArgs {
+    int32_t G, N, T, n_episodes, tuples;
+    int32_t waves_per_block, total_waves;
+    int32_t lut_lds_bytes;          // LDS-staged part of the LUT image: rows16 [tuples][N], then aq / sct [N][64] doubles
+    int32_t aq_off, price_off;      // byte offsets in the image: aq (inside the staged part), price [tuples] (HBM only)
+    int32_t game_lds_bytes;         // per wave: tables | greedy-action bytes | G table | visit histogram
+    int32_t tab_off[kTupMaxN];      // element offset of agent i's window (+ 2 spill rows) in the per-game table region
+    int32_t am_off, am_off_i[kTupMaxN];      // byte offsets
+    int32_t g_off;                  // byte offset of G [tuples + 1] u32
+    int32_t hist_off, hist_off_i[kTupMaxN], hist_dwords;   // histogram: byte offset, per-agent dword offsets, total dwords
+    int32_t row_lo[kTupMaxN], win_rows[kTupMaxN];
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[kTupMaxN];
+    void* q; int32_t* counter; double* state;
+    const unsigned char* lut;       // device: the LUT image
+    double* sum_reward; double* sum_action;      // device [n_episodes][N] sums over games (zeroed by the host) or null
+    int32_t* next_game;             // device: work counter of the launch, zeroed by the host
+    const double* inj_u; const int8_t* inj_choice;   // parity mode: [n_episodes][T][N][G], or null (Philox)
+    uint64_t seed, game_offset, first_episode;
+    double eps[kTupMaxEpisodes][kTupMaxN];
+};
+int launch_tuple_lut(const TupleArgs& a, unsigned char* out, hipStream_t s);
+int launch_tuple(const TupleArgs& a, int q_dtype, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f32(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f64(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+
 int launch_generic(const GenericArgs& a, int q_dtype, hipStream_t s);
 int launch_finalize_logs(double* sum_reward, double* sum_action, int n, int G, hipStream_t s);
 int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s);

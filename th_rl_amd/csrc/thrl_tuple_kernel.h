@@ -1,0 +1,494 @@
+// thrl_tuple_kernel.h -- fused episode kernel for 1-4 QTable agents with INDIVIDUAL grids: ONE WAVEFRONT PER GAME,
+// tables in LDS ("tuple-chain" kernel; template body, instantiated in thrl_tuple_f32.hip / thrl_tuple_f64.hip).
+//
+// The LDS-resident path for what the two-agent wave kernel (thrl_wave_kernel.h) does not take: other than two
+// agents, per-agent state / action grids, per-agent max_state (the reference allows any nplayers and any QTable
+// per agent: th_rl/trainer.py:21-23, agents.py:13-28).  Same semantics as thrl_generic.hip and bit-identical results
+// to it and to the oracle: trainer.train_one's loop (trainer.py:46-70) with QTable.sample_action (agents.py:80-89),
+// scale (:51-57), NoisyPriceState.step (environments.py:25-39, noise_prob == 0), ReplayBuffer append / replay / empty
+// and QTable.train_net (agents.py:59-78) for `n_episodes` episodes per launch.
+//
+// Idea: without noise the state after a step is a function of that step's ACTION TUPLE, so a game's state is a
+// small integer tau = ((a0*A1 + a1)*A2 + a2)*A3 + a3 (< 4,096) and everything the loop needs is a table over it:
+//   * per block, staged in LDS once: rows16[tau][i] = window-local row of the price after tuple tau for agent i
+//     (play row: float32 encode, trainer.py:53 | train row: float64 encode, agents.py:62,66 -- both kept);
+//     per-action quantities (a/b)*scale_i(k) and scale_i(k)/T; the price per tuple stays in HBM (L2), it is only
+//     gathered lane-parallel;
+//   * per game and episode: the greedy action of every table row (lane = row; tables are frozen during play), composed
+//     into G[tau] = the agents' greedy actions in state tau, packed one per byte;
+//   * play = a chain of T steps on the SCALAR unit: a = explore ? choice : G[tau] per byte, tau' = mixed radix of a --
+//     one LDS read, two v_readlane, one v_writelane and ~3N scalar instructions per step;
+//   * everything else is lane-parallel over the steps (lane = step): Philox draws, rows, prices, rewards, the
+//     old-value snapshot (agents.py:67), the log sums;
+//   * replay = train_net's serial loop (agents.py:68-76) for ALL agents at once: agent i owns lanes 16i..16i+15, a
+//     lane reads ceil(A_i/16) columns of the next-state row, four DPP steps give the row maximum, lane 16i stores
+//     the TD value; step operands reach the 16-lane rows by ds_bpermute per 16 steps and row_newbcast DPP per step.
+//     Strictly one transition at a time per agent, in order: no hazard analysis needed.
+//   * visit counters: u16 histogram in LDS beside the tables, applied to the int32 counters once per launch.
+#pragma once
+#include <type_traits>
+#include "thrl_kernels.h"
+
+namespace thrl {
+namespace tup {
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <typename QT> __device__ __forceinline__ QT lds_load(unsigned addr) {
+    typedef __attribute__((address_space(3))) QT lds_t;
+    return *(const lds_t*)(uintptr_t)addr;
+}
+template <typename QT> __device__ __forceinline__ void lds_store(unsigned addr, QT v) {
+    typedef __attribute__((address_space(3))) QT lds_t;
+    *(lds_t*)(uintptr_t)addr = v;
+}
+__device__ __forceinline__ unsigned bperm(unsigned byte_sel, unsigned v) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_sel, (int)v);
+}
+template <int CTRL> __device__ __forceinline__ uint32_t dpp32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ float dppf(float v) { return __builtin_bit_cast(float, dpp32<CTRL>(__builtin_bit_cast(uint32_t, v))); }
+template <int CTRL> __device__ __forceinline__ double dppd(double v) {
+    return __hiloint2double((int)dpp32<CTRL>((uint32_t)__double2hiint(v)), (int)dpp32<CTRL>((uint32_t)__double2loint(v)));
+}
+// maximum over each aligned 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row16_allmax(float v) {
+    v = fmaxf(v, dppf<0xB1>(v));          // quad_perm [1,0,3,2]
+    v = fmaxf(v, dppf<0x4E>(v));          // quad_perm [2,3,0,1]
+    v = fmaxf(v, dppf<0x141>(v));         // row_half_mirror
+    v = fmaxf(v, dppf<0x140>(v));         // row_mirror
+    return v;
+}
+__device__ __forceinline__ double row16_allmax(double v) {
+    v = fmax(v, dppd<0xB1>(v));
+    v = fmax(v, dppd<0x4E>(v));
+    v = fmax(v, dppd<0x141>(v));
+    v = fmax(v, dppd<0x140>(v));
+    return v;
+}
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+// Sum FOUR per-lane doubles over the 64 lanes in one pass ("transpose" reduction): returns, in every lane L, the wave
+// total of quantity (L & 3).  DPP moves and two permlane swaps, no LDS traffic (a __shfl_xor tree is 12 ds_bpermute
+// per value: 24 LDS cycles each).
+__device__ __forceinline__ double wave_sum4(double q0, double q1, double q2, double q3, int lane) {
+    const bool odd = lane & 1;
+    const double k0 = odd ? q1 : q0, k1 = odd ? q3 : q2;
+    const double s0 = odd ? q0 : q1, s1 = odd ? q2 : q3;
+    const double a0 = k0 + dppd<0xB1>(s0);                    // quad_perm [1,0,3,2]
+    const double a1 = k1 + dppd<0xB1>(s1);
+    const bool b1 = lane & 2;
+    const double kk = b1 ? a1 : a0, ss = b1 ? a0 : a1;
+    double v = kk + dppd<0x4E>(ss);                           // quad_perm [2,3,0,1]
+    v = v + dppd<0x124>(v);                                   // row_ror:4
+    v = v + dppd<0x128>(v);                                   // row_ror:8
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane16_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane16_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
+    {
+        unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        unsigned lo2 = lo, hi2 = hi;
+        asm("" : "+v"(lo2), "+v"(hi2));
+        const v2u rl = __builtin_amdgcn_permlane32_swap(lo, lo2, false, false);
+        const v2u rh = __builtin_amdgcn_permlane32_swap(hi, hi2, false, false);
+        const unsigned rlx = rl.x, rly = rl.y, rhx = rh.x, rhy = rh.y;
+        v = __hiloint2double((int)rhx, (int)rlx) + __hiloint2double((int)rhy, (int)rly);
+    }
+    return v;
+}
+__device__ __forceinline__ float neg_inf(float) { return -INFINITY; }
+__device__ __forceinline__ double neg_inf(double) { return -(double)INFINITY; }
+
+// operands of a transition that do not depend on the live next_max (thrl_device.h td_value):
+// float : c1 = fma(alpha, reward, (1-alpha)*old_value);  double: reward and (1-alpha)*old_value
+template <typename QT> struct Ops;
+template <> struct Ops<float> {
+    uint32_t c1;
+    __device__ __forceinline__ void set(float ov, double re, const TdCoef& c) {
+        c1 = __builtin_bit_cast(uint32_t, __fmaf_rn(c.alpha_f, (float)re, __fmul_rn(c.one_minus_alpha_f, ov)));
+    }
+    __device__ __forceinline__ void gather(unsigned sel, const Ops<float>& src, bool mine) { const uint32_t v = bperm(sel, src.c1); if (mine) c1 = v; }
+    template <int J> __device__ __forceinline__ Ops<float> bcast() const { Ops<float> o; o.c1 = dpp32<0x150 + J>(c1); return o; }
+    __device__ __forceinline__ float value(float nm, float alpha_gamma, float, float) const {
+        return __fmaf_rn(alpha_gamma, nm, __builtin_bit_cast(float, c1));
+    }
+};
+template <> struct Ops<double> {
+    uint32_t r_lo, r_hi, t_lo, t_hi;
+    __device__ __forceinline__ void set(double ov, double re, const TdCoef& c) {
+        const double t4 = __dmul_rn(c.one_minus_alpha, ov);
+        r_lo = (uint32_t)__double2loint(re); r_hi = (uint32_t)__double2hiint(re);
+        t_lo = (uint32_t)__double2loint(t4); t_hi = (uint32_t)__double2hiint(t4);
+    }
+    __device__ __forceinline__ void gather(unsigned sel, const Ops<double>& s, bool mine) {
+        const uint32_t a = bperm(sel, s.r_lo), b = bperm(sel, s.r_hi), c = bperm(sel, s.t_lo), d = bperm(sel, s.t_hi);
+        if (mine) { r_lo = a; r_hi = b; t_lo = c; t_hi = d; }
+    }
+    template <int J> __device__ __forceinline__ Ops<double> bcast() const {
+        Ops<double> o;
+        o.r_lo = dpp32<0x150 + J>(r_lo); o.r_hi = dpp32<0x150 + J>(r_hi); o.t_lo = dpp32<0x150 + J>(t_lo); o.t_hi = dpp32<0x150 + J>(t_hi);
+        return o;
+    }
+    __device__ __forceinline__ double value(double nm, double, double alpha, double gamma) const {
+        const double re = __hiloint2double((int)r_hi, (int)r_lo), t4 = __hiloint2double((int)t_hi, (int)t_lo);
+        return __dadd_rn(t4, __dmul_rn(alpha, __dadd_rn(re, __dmul_rn(gamma, nm))));      // agents.py:72-74
+    }
+};
+
+// one transition of every agent (agents.py:68-76): J = position inside the 16-step block (row_newbcast lane)
+template <typename QT, int J>
+__device__ __forceinline__ void replay_step(uint32_t xw, const Ops<QT>& xo, unsigned tab_me, unsigned hist_me, unsigned a_bytes, unsigned col_b0,
+                                            unsigned col_b1, unsigned col_b2, unsigned col_b3, int ncol, bool storer, bool count,
+                                            QT alpha_gamma, QT alpha, QT gamma) {
+    const uint32_t w = dpp32<0x150 + J>(xw);                    // this row's agent, step J of the block: ns | cell << 8
+    const Ops<QT> o = xo.template bcast<J>();
+    const unsigned ns = w & 0xFFu, cell = (w >> 8) & 0xFFFFu;
+    const unsigned rowa = tab_me + ns * a_bytes;
+    QT m = lds_load<QT>(rowa + col_b0);
+    if (ncol > 1) m = m > lds_load<QT>(rowa + col_b1) ? m : lds_load<QT>(rowa + col_b1);
+    if (ncol > 2) { const QT v = lds_load<QT>(rowa + col_b2); m = v > m ? v : m; }
+    if (ncol > 3) { const QT v = lds_load<QT>(rowa + col_b3); m = v > m ? v : m; }
+    m = row16_allmax(m);
+    const QT val = o.value(m, alpha_gamma, alpha, gamma);
+    if (storer) {
+        lds_store<QT>(tab_me + cell * (unsigned)sizeof(QT), val);
+        if (count) {
+            typedef __attribute__((address_space(3))) unsigned lds_u32;
+            __hip_atomic_fetch_add((lds_u32*)(uintptr_t)(hist_me + (cell >> 1) * 4u), 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename QT, int N, int NSEG>
+__global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int T = a.T, tuples = a.tuples;
+    {   // stage the LUT (rows per tuple and agent, per-action quantities) once per block
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.lut);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        for (int k = threadIdx.x; k < (a.lut_lds_bytes >> 2); k += blockDim.x) dst[k] = src[k];
+    }
+    __syncthreads();
+    const unsigned short* rows16 = reinterpret_cast<const unsigned short*>(smem);                  // [tuples][N]
+    const double* lut_aq = reinterpret_cast<const double*>(smem + a.aq_off);                        // [N][64]
+    const double* lut_sct = lut_aq + N * 64;                                                         // [N][64]
+    const double* price_lut = reinterpret_cast<const double*>(a.lut + a.price_off);                 // [tuples], HBM / L2
+    unsigned char* game = smem + a.lut_lds_bytes + (size_t)wib * a.game_lds_bytes;
+    QT* const tabs = reinterpret_cast<QT*>(game);
+    unsigned char* const am = game + a.am_off;
+    uint32_t* const gt = reinterpret_cast<uint32_t*>(game + a.g_off);                                // [tuples + 1]
+    typedef unsigned __attribute__((may_alias)) hist_u32;
+    hist_u32* const hist = reinterpret_cast<hist_u32*>(game + a.hist_off);
+
+    // replay ("exec") layout: agent my_ag owns the 16-lane row `lane >> 4`
+    const int my_ag = lane >> 4, l16 = lane & 15;
+    const bool ag_ok = my_ag < N;
+    const AgentParams& pme = a.ag[ag_ok ? my_ag : 0];
+    const int A_me = pme.n_actions;
+    const unsigned a_bytes = (unsigned)A_me * (unsigned)sizeof(QT);
+    const unsigned tab_me = lds_addr(tabs + a.tab_off[ag_ok ? my_ag : 0]);
+    const unsigned hist_me = lds_addr(hist + a.hist_off_i[ag_ok ? my_ag : 0]);
+    const unsigned col_b0 = (unsigned)min(l16, A_me - 1) * (unsigned)sizeof(QT), col_b1 = (unsigned)min(l16 + 16, A_me - 1) * (unsigned)sizeof(QT);
+    const unsigned col_b2 = (unsigned)min(l16 + 32, A_me - 1) * (unsigned)sizeof(QT), col_b3 = (unsigned)min(l16 + 48, A_me - 1) * (unsigned)sizeof(QT);
+    int amax = 1;
+#pragma unroll
+    for (int i = 0; i < N; i++) amax = max(amax, a.ag[i].n_actions);
+    const int ncol = (amax + 15) >> 4;
+    const bool storer = ag_ok && l16 == 0;
+    const TdCoef tc_me = td_coef(pme);
+    const QT alpha_me = std::is_same<QT, float>::value ? (QT)tc_me.alpha_f : (QT)tc_me.alpha;
+    const QT gamma_me = (QT)pme.gamma;
+    const QT ag_me = std::is_same<QT, float>::value ? (QT)tc_me.alpha_gamma_f : (QT)0;
+
+    // per-wave log sums: slot = episode * 8 + k (k < N: reward of agent k; 4 <= k < 4 + N: action), lane = slot & 63
+    double accd[4] = {0.0, 0.0, 0.0, 0.0};
+
+    int g_claim = 0;
+    if (lane == 0) g_claim = atomicAdd(a.next_game, 1);
+    for (;;) {
+        const int g = __builtin_amdgcn_readfirstlane(g_claim);
+        if (g >= a.G) break;
+        if (lane == 0) g_claim = atomicAdd(a.next_game, 1);
+        const uint64_t gid = a.game_offset + (uint64_t)g;
+        QT* __restrict__ qg = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride;
+        const double price0 = a.state[g];
+
+        // ---- tables -> LDS (window rows are contiguous in HBM), initial state -> local rows (window or spill)
+        int init_play[N], init_train[N], spill_p[N], spill_t[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const AgentParams& p = a.ag[i];
+            const int A = p.n_actions, W = a.win_rows[i], lo = a.row_lo[i];
+            QT* t = tabs + a.tab_off[i];
+            const QT* src = qg + p.table_off + lo * A;
+            for (int k = lane; k < W * A; k += 64) t[k] = src[k];
+            const int sp = __builtin_amdgcn_readfirstlane(encode32(price0, p)), st = __builtin_amdgcn_readfirstlane(encode64(price0, p));
+            spill_p[i] = spill_t[i] = -1;
+            if (sp >= lo && sp < lo + W) init_play[i] = sp - lo; else { spill_p[i] = sp; init_play[i] = W; }
+            if (st == sp) init_train[i] = init_play[i];
+            else if (st >= lo && st < lo + W) init_train[i] = st - lo;
+            else { spill_t[i] = st; init_train[i] = W + 1; }
+            if (lane < A) {
+                // (both spill rows are always filled: a row nobody addresses is never read)
+                t[W * A + lane] = qg[p.table_off + (spill_p[i] >= 0 ? spill_p[i] : 0) * A + lane];
+                t[(W + 1) * A + lane] = qg[p.table_off + (spill_t[i] >= 0 ? spill_t[i] : 0) * A + lane];
+            }
+        }
+        for (int k = lane; k < a.hist_dwords; k += 64) hist[k] = 0u;
+        __builtin_amdgcn_wave_barrier();
+
+        int tau = tuples;                    // current state: action tuple of the last step; `tuples` = the launch's initial state
+        for (int e = 0; e < a.n_episodes; e++) {
+            const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
+
+            // ---- (a) greedy action of every local row (first max wins, numpy.argmax: agents.py:85), lane = row
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int A = a.ag[i].n_actions, R = a.win_rows[i] + 2;
+                const QT* t = tabs + a.tab_off[i];
+                for (int base = 0; base < R; base += 64) {
+                    const int row = min(base + lane, R - 1);
+                    const QT* r = t + row * A;
+                    QT b = r[0];
+                    int bi = 0;
+                    // (eight loads in flight per round trip instead of one: the row reads do not depend on the compares)
+                    int j = 1;
+                    for (; j + 8 <= A; j += 8) {
+                        QT v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = r[j + u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (v[u] > b) { b = v[u]; bi = j + u; }
+                    }
+                    for (; j < A; j++) { const QT v = r[j]; if (v > b) { b = v; bi = j; } }
+                    if (base + lane < R) am[a.am_off_i[i] + row] = (unsigned char)bi;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- (b) G[tau] = the agents' greedy actions in state tau, one per byte (entry `tuples`: the initial state)
+            for (int base = 0; base <= tuples; base += 256) {         // four batches of 64 tuples in flight
+                int row[4][N];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int tq = min(base + u * 64 + lane, tuples);
+#pragma unroll
+                    for (int i = 0; i < N; i++) row[u][i] = tq == tuples ? init_play[i] : (int)(rows16[tq * N + i] & 0xFFu);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t packed = 0u;
+#pragma unroll
+                    for (int i = 0; i < N; i++) packed |= (uint32_t)am[a.am_off_i[i] + row[u][i]] << (8 * i);
+                    if (base + u * 64 + lane <= tuples) gt[base + u * 64 + lane] = packed;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- (c) draws, lane = step: Mw byte i = 0xFF where agent i explores, Cw byte i = its random choice
+            uint32_t Mw[NSEG], Cw[NSEG];
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int tt = min(seg * 64 + lane, T - 1);
+                uint32_t mw = 0u, cw = 0u;
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const AgentParams& p = a.ag[i];
+                    double u; uint32_t ch;
+                    if (a.inj_u) {           // parity mode: the reference's recorded draws [E][T][N][G] (agents.py:81-82)
+                        const size_t k = (((size_t)e * T + tt) * N + i) * (size_t)a.G + (size_t)g;
+                        u = a.inj_u[k]; ch = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(p.n_actions - 1));
+                    } else {
+                        const u32x4 x = draw(a.seed, gid, eg, (uint32_t)tt, (uint32_t)(i >> 1));
+                        u = u01_32((i & 1) ? x.z : x.x);
+                        ch = __umulhi((i & 1) ? x.w : x.y, (uint32_t)p.n_actions);
+                    }
+                    if (u < a.eps[e][i]) mw |= 0xFFu << (8 * i);
+                    cw |= ch << (8 * i);
+                }
+                Mw[seg] = mw; Cw[seg] = cw;
+            }
+
+            // ---- (d) play: the serial chain, on the scalar unit.  seq[seg] lane t = state (tuple) step t was played in
+            uint32_t seq[NSEG];
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                seq[seg] = 0u;
+                const int n = min(64, T - seg * 64);
+                for (int tl = 0; tl < n; tl++) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)Mw[seg], tl), c = (uint32_t)__builtin_amdgcn_readlane((int)Cw[seg], tl);
+                    const uint32_t ap = (c & m) | (w & ~m);
+                    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(seq[seg]) : "s"(tau), "s"(tl));
+                    int nt = 0;
+#pragma unroll
+                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)((ap >> (8 * i)) & 0xFFu);
+                    tau = nt;
+                }
+            }
+            const int tau_end = tau;
+
+            // ---- (e) lane-parallel over the steps: actions, rows, prices, rewards, old-value snapshot (agents.py:67), logs
+            uint32_t word[NSEG][N];           // ns | cell << 8 (| valid << 31)
+            Ops<QT> ops[NSEG][N];
+            double lr[N], la[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) { lr[i] = 0.0; la[i] = 0.0; }
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                const int tt = seg * 64 + lane;
+                const bool valid = tt < T;
+                const int tq = valid ? (int)seq[seg] : tau_end;
+                int nxt = __shfl_down((int)seq[seg], 1, 64);
+                if (seg + 1 < NSEG) { if (lane == 63) nxt = __builtin_amdgcn_readlane((int)seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
+                if (tt + 1 >= T) nxt = tau_end;
+                const uint32_t w = gt[tq];
+                const uint32_t ap = (Cw[seg] & Mw[seg]) | (w & ~Mw[seg]);
+                const double price = price_lut[nxt];
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const AgentParams& p = a.ag[i];
+                    const int A = p.n_actions;
+                    const uint32_t act = valid ? ((ap >> (8 * i)) & 0xFFu) : 0u;
+                    const uint32_t srow = tq == tuples ? (uint32_t)init_train[i] : (uint32_t)(rows16[tq * N + i] >> 8);
+                    const uint32_t ns = (uint32_t)(rows16[nxt * N + i] >> 8);
+                    const uint32_t cell = valid ? srow * (uint32_t)A + act : 0u;
+                    const double aq = lut_aq[i * 64 + act];
+                    const double re = __dmul_rn(price, aq);                       // environments.py:33
+                    const QT ov = tabs[a.tab_off[i] + cell];
+                    ops[seg][i].set(ov, re, td_coef(p));
+                    word[seg][i] = ns | (cell << 8);
+                    if (valid) { lr[i] += re; la[i] += lut_sct[i * 64 + act]; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- (f) replay = train_net's loop (agents.py:68-76), every agent at once, one transition per agent at a time
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int base_t = seg * 64 + b * 16;
+                    if (base_t >= T) break;
+                    const unsigned sel = (unsigned)(b * 16 + l16) << 2;
+                    uint32_t xw = 0u;
+                    Ops<QT> xo = ops[seg][0];
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        const uint32_t v = bperm(sel, word[seg][i]);
+                        if (my_ag == i) xw = v;
+                        xo.gather(sel, ops[seg][i], my_ag == i);
+                    }
+                    const int nb = min(16, T - base_t);
+                    const bool cnt = a.counter != nullptr;
+#define THRL_TUP_STEP(J) if ((J) < nb) replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cnt, ag_me, alpha_me, gamma_me);
+                    THRL_TUP_STEP(0) THRL_TUP_STEP(1) THRL_TUP_STEP(2) THRL_TUP_STEP(3) THRL_TUP_STEP(4) THRL_TUP_STEP(5) THRL_TUP_STEP(6) THRL_TUP_STEP(7)
+                    THRL_TUP_STEP(8) THRL_TUP_STEP(9) THRL_TUP_STEP(10) THRL_TUP_STEP(11) THRL_TUP_STEP(12) THRL_TUP_STEP(13) THRL_TUP_STEP(14) THRL_TUP_STEP(15)
+#undef THRL_TUP_STEP
+                }
+            }
+
+            // ---- (g) log sums of this game and episode into the wave accumulators (mean over games: host / finalize)
+            {
+                // lane L of tr: reward total of agent L & 3; of ta: action total (already divided by T per step)
+                const double tr = __ddiv_rn(wave_sum4(lr[0], N > 1 ? lr[N > 1 ? 1 : 0] : 0.0, N > 2 ? lr[N > 2 ? 2 : 0] : 0.0,
+                                                      N > 3 ? lr[N > 3 ? 3 : 0] : 0.0, lane), (double)T);
+                const double ta = wave_sum4(la[0], N > 1 ? la[N > 1 ? 1 : 0] : 0.0, N > 2 ? la[N > 2 ? 2 : 0] : 0.0,
+                                            N > 3 ? la[N > 3 ? 3 : 0] : 0.0, lane);
+                // slot e*8 + k lives in lane (e*8 + k) & 63 of accd[(e*8 + k) >> 6]: lanes with (lane >> 3) == (e & 7)
+                const int k = lane & 7;
+                const double v = k < 4 ? tr : ta;              // (lane & 3) == (k & 3): the right agent's total
+                if ((lane >> 3) == (e & 7) && (k & 3) < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if ((e >> 3) == r) accd[r] += v;
+                }
+            }
+        }
+
+        // ---- tables back to HBM, env state, visit counters
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const AgentParams& p = a.ag[i];
+            const int A = p.n_actions, W = a.win_rows[i], lo = a.row_lo[i];
+            const QT* t = tabs + a.tab_off[i];
+            QT* dst = qg + p.table_off + lo * A;
+            for (int k = lane; k < W * A; k += 64) dst[k] = t[k];
+            if (lane < A) {
+                if (spill_p[i] >= 0) qg[p.table_off + spill_p[i] * A + lane] = t[W * A + lane];
+                if (spill_t[i] >= 0) qg[p.table_off + spill_t[i] * A + lane] = t[(W + 1) * A + lane];
+            }
+            if (a.counter) {
+                int32_t* cg = a.counter + (int64_t)g * a.stride + p.table_off;
+                const hist_u32* h = hist + a.hist_off_i[i];
+                for (int k = lane; k < W * A; k += 64) {
+                    const unsigned n = (h[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                    if (n) cg[lo * A + k] += (int32_t)n;
+                }
+                if (lane < 2 * A) {
+                    const int which = lane >= A, col = lane - which * A, k = (W + which) * A + col;
+                    const int grow = which ? spill_t[i] : spill_p[i];
+                    const unsigned n = (h[k >> 1] >> ((k & 1) << 4)) & 0xFFFFu;
+                    if (grow >= 0 && n) cg[grow * A + col] += (int32_t)n;
+                }
+            }
+        }
+        if (lane == 0 && a.n_episodes > 0) a.state[g] = price_lut[tau];
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- the wave's log sums -> the launch's [E][N] sums (float64 atomics: the mean logs are compared to 1e-12)
+    if (a.sum_reward) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int slot = r * 64 + lane, e = slot >> 3, k = slot & 7;
+            if (e < a.n_episodes && (k & 3) < N && accd[r] != 0.0) {
+                if (k < 4) atomicAdd(&a.sum_reward[(size_t)e * N + k], accd[r]);
+                else atomicAdd(&a.sum_action[(size_t)e * N + (k - 4)], accd[r]);
+            }
+        }
+    }
+}
+
+template <typename QT, int N>
+static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    const int nseg = (a.T + 63) / 64;
+#define THRL_TUP_LAUNCH(NS)                                                                                          \
+    {                                                                                                                \
+        auto kern = k_tuple_episodes<QT, N, NS>;                                                                     \
+        if (lds > 64 * 1024) {                                                                                       \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+            if (e != hipSuccess) return (int)e;                                                                      \
+        }                                                                                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, a);                                                \
+        return (int)hipGetLastError();                                                                               \
+    }
+    if (nseg <= 1) THRL_TUP_LAUNCH(1)
+    if (nseg == 2) THRL_TUP_LAUNCH(2)
+    THRL_TUP_LAUNCH(4)
+#undef THRL_TUP_LAUNCH
+}
+
+template <typename QT>
+static int launch_tuple_t(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    switch (a.N) {
+        case 1: return launch_tuple_n<QT, 1>(a, grid, block, lds, s);
+        case 2: return launch_tuple_n<QT, 2>(a, grid, block, lds, s);
+        case 3: return launch_tuple_n<QT, 3>(a, grid, block, lds, s);
+        case 4: return launch_tuple_n<QT, 4>(a, grid, block, lds, s);
+    }
+    return -1;
+}
+
+}  // namespace tup
+}  // namespace thrl
