@@ -685,3 +685,56 @@ def test_full_size_properties_65536_games_neural(pair):
     assert r.shape == (E, 2) and np.isfinite(r).all() and (r > 4.0).all() and (r < 24.0).all()
     a = out["action_log"]
     assert ((a >= 0.2) & (a <= 0.4)).all()
+
+
+# ---------------------------------------------------------------- the tuple-chain kernel for games with neural policies
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("label,agents,T", [
+    ("q_vs_reinforce", [dict(Q_AGENT, min_memory=30, capacity=64), dict(R_AGENT, min_memory=70, entropy=0.01)], 30),
+    ("reinforce_vs_q", [dict(R_AGENT, min_memory=50), dict(Q_AGENT, min_memory=25, capacity=500, actions=15)], 25),
+    ("two_reinforce", [dict(R_AGENT, min_memory=60, entropy=0.02), dict(R_AGENT, min_memory=35)], 20),
+    ("q_vs_actorcritic_T70", [dict(Q_AGENT, min_memory=70), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
+                                                             "action_range": [0.2, 0.4], "min_memory": 140}], 70),
+    ("reinforce_vs_actorcritic", [dict(R_AGENT, min_memory=60), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
+                                                                 "action_range": [0.2, 0.4], "min_memory": 45}], 15),
+])
+def test_policy_tuple_kernel_equals_general_kernel_and_operator_loop(label, agents, T, dtype):
+    """thrl_ptuple.hip (two-agent noise-free games with discrete policies: the state is carried as the action pair, policy
+    CDFs are looked up) against the general fused kernel (k_mixed_wave) AND the unfused operator loop, on the same seeds over
+    several network updates and two calls: per-game logs, tables, counters, state, replay rings, epsilon, network parameters
+    and Adam state all bit-identical."""
+    from th_rl_amd.mixed import MixedGameBatch
+    config = {"agents": [dict(x) for x in agents], "environment": dict(ENV, max_steps=T, noise_prob=0.0)}
+    G, E = 7, 9
+    a = MixedGameBatch(config, n_games=G, dtype=dtype, seed=33, game_offset=11).init_tables()
+    b = MixedGameBatch(config, n_games=G, dtype=dtype, seed=33, game_offset=11).init_tables()
+    c = MixedGameBatch(config, n_games=G, dtype=dtype, seed=33, game_offset=11).init_tables()
+    b.tuple_kernel = False
+    ra1 = a.run(4, fused=True); ra2 = a.run(E - 4, fused=True)
+    rb = b.run(E, fused=True)
+    rc = c.run(E, fused=False)
+    assert ra1["episode_kernel"] == "tuple" and ra2["episode_kernel"] == "tuple" and rb["episode_kernel"] == "wave", label
+    for other, ro in ((b, rb), (c, rc)):
+        assert np.array_equal(np.concatenate([ra1["game_reward_log"], ra2["game_reward_log"]]), ro["game_reward_log"]), label
+        assert np.array_equal(np.concatenate([ra1["game_action_log"], ra2["game_action_log"]]), ro["game_action_log"]), label
+        assert np.array_equal(a.tables_numpy(), other.tables_numpy()) and np.array_equal(a.counters_numpy(), other.counters_numpy())
+        assert np.array_equal(a.states_numpy(), other.states_numpy())
+        assert a.eps == other.eps and a.count == other.count and a.episode == other.episode
+        for i in a.nn:
+            assert a.nn[i].step == other.nn[i].step and a.nn[i].step >= 1
+            assert np.array_equal(a.nn[i].params.cpu().numpy(), other.nn[i].params.cpu().numpy()), label
+            assert np.array_equal(a.nn[i].adam_m.cpu().numpy(), other.nn[i].adam_m.cpu().numpy())
+            # the rings hold the same transitions where both are filled (the QTable agent's ring is not used by the tuple kernel)
+            n = min(a.count[i], a.buf_len[i])
+            for k in ("price", "action", "reward", "nprice"):
+                assert np.array_equal(a.buf[i][k][:, :n].cpu().numpy(), other.buf[i][k][:, :n].cpu().numpy()), (label, k)
+
+
+def test_policy_tuple_kernel_is_not_taken_with_noise_or_unfit_buffers():
+    from th_rl_amd.mixed import MixedGameBatch
+    base = [dict(Q_AGENT, min_memory=25), dict(R_AGENT, min_memory=50)]
+    noisy = MixedGameBatch({"agents": [dict(x) for x in base], "environment": dict(ENV, max_steps=25, noise_prob=0.05)}, n_games=4, seed=1).init_tables()
+    assert noisy.run(2, fused=True)["episode_kernel"] == "wave"
+    spans = MixedGameBatch({"agents": [dict(Q_AGENT, min_memory=60), dict(R_AGENT, min_memory=50)],
+                            "environment": dict(ENV, max_steps=25)}, n_games=4, seed=1).init_tables()     # QTable trains every 3rd episode
+    assert spans.run(2, fused=True)["episode_kernel"] == "wave"

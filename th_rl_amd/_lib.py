@@ -72,7 +72,7 @@ class Mixed(ctypes.Structure):
         ("sweep_gamma", ctypes.c_void_p), ("sweep_alpha", ctypes.c_void_p),
         ("sweep_eps_end", ctypes.c_void_p), ("sweep_eps_step", ctypes.c_void_p),
         ("sweep_eps", ctypes.c_void_p), ("sweep_noise_prob", ctypes.c_void_p),
-        ("policy_tab", ctypes.c_void_p), ("policy_tab_bytes", ctypes.c_size_t),
+        ("policy_tab", ctypes.c_void_p), ("policy_tab_bytes", ctypes.c_size_t), ("flags", ctypes.c_int32),
     ]
 
 

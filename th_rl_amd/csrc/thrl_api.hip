@@ -896,6 +896,122 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
 }
 
+// ---- the tuple-chain kernel for two-agent games with discrete neural policies (thrl_ptuple.hip)
+struct PTuplePlan { bool ok; char why[160]; PTupleArgs a; int waves_per_block, blocks_per_cu; size_t scratch_bytes; };
+constexpr size_t kPTupleLutRegion = 64 * 1024;     // head of thrl_mixed.policy_tab: LUT image + the launch's work counter (last 64 bytes)
+
+static double h_scale_kind(int k, const thrl_cfg* c, int i, int kind) {
+    if (kind == 0) return h_scale(k, c, i);
+    double x = (double)k / (double)c->n_actions[i];             // Reinforce.scale (agents.py:153-157): action / actions
+    x = x * (c->act_hi[i] - c->act_lo[i]);
+    return x + c->act_lo[i];
+}
+
+static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
+    PTuplePlan p;
+    memset(&p, 0, sizeof(p));
+#define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
+    PTupleArgs& a = p.a;
+    if (c->n_agents != 2) NO("not a two-agent game");
+    if (c->noise_prob > 0.0) NO("environment noise");
+    if (mx->sweep_gamma || mx->sweep_alpha || mx->sweep_eps_end || mx->sweep_eps_step || mx->sweep_eps || mx->sweep_noise_prob) NO("per-game sweeps");
+    const int T = c->max_steps;
+    if (T > 256) NO("more than 256 steps per episode");
+    a.qi = -1; a.n_r = 0;
+    for (int i = 0; i < 2; i++) {
+        a.kind[i] = mx->kind[i];
+        if (mx->kind[i] == 0) {
+            if (a.qi >= 0) NO("no neural agent");
+            a.qi = i;
+            if (c->n_actions[i] > 64) NO("QTable agent with more than 64 actions");
+            // train_net trains -- and empties the ring -- after every episode (agents.py:60,77)
+            if (!(mx->buf_len[i] > 0 && mx->min_memory[i] <= T && T <= mx->buf_len[i] && mx->count[i] == 0)) NO("QTable replay buffer does not train once per episode");
+        } else if (mx->kind[i] == 1 || mx->kind[i] == 2) {
+            if (c->n_actions[i] > 32) NO("neural agent with more than 32 actions");
+            if (mx->buf_len[i] < T) NO("a neural agent's replay ring is shorter than an episode");
+            a.ri[a.n_r++] = i;
+        } else NO("continuous agent");
+    }
+    if (a.n_r == 0) NO("no neural agent");
+    const long tuples = (long)c->n_actions[0] * c->n_actions[1];
+    if (tuples > kTupMaxTuples) NO("more than 4,096 action pairs");
+    a.tuples = (int)tuples; a.T = T;
+    // distinct float32 prices, in order of first occurrence (the device repeats this enumeration: k_ptuple_lut), and the
+    // QTable agent's row window
+    static thread_local float seen[kTupMaxTuples];
+    int npid = 0, lo = 1 << 30, hi = -1;
+    const double ratio = c->env_a / c->env_b;
+    for (int a0 = 0; a0 < c->n_actions[0]; a0++)
+        for (int a1 = 0; a1 < c->n_actions[1]; a1++) {
+            double Q = 0.0;
+            Q = Q + ratio * h_scale_kind(a0, c, 0, mx->kind[0]);
+            Q = Q + ratio * h_scale_kind(a1, c, 1, mx->kind[1]);
+            double price = c->env_a - c->env_b * Q;
+            if (!(price > 0.0)) price = 0.0;
+            const float x = (float)price;
+            int j = 0;
+            while (j < npid && memcmp(&seen[j], &x, 4) != 0) j++;
+            if (j == npid) seen[npid++] = x;
+            if (a.qi >= 0) {
+                const int r64 = h_encode64(price, c, a.qi), r32 = h_encode32(price, c, a.qi);
+                if (r64 < 0 || r64 > c->n_states[a.qi] || r32 < 0 || r32 > c->n_states[a.qi]) NO("price outside the table on the action grid");
+                lo = r64 < lo ? r64 : lo; lo = r32 < lo ? r32 : lo;
+                hi = r64 > hi ? r64 : hi; hi = r32 > hi ? r32 : hi;
+            }
+        }
+    if (npid > 2048) NO("more than 2,048 distinct prices");
+    a.npid = npid;
+    int amax = 0;
+    for (int r = 0; r < a.n_r; r++) amax = c->n_actions[a.ri[r]] > amax ? c->n_actions[a.ri[r]] : amax;
+    const int apad = amax <= 24 ? 24 : 32;
+    const int esz = c->q_dtype == 1 ? 8 : 4;
+    size_t off = 0;
+    if (a.qi >= 0) {
+        a.row_lo = lo; a.win_rows = hi - lo + 1;
+        if (a.win_rows + 2 > 256) NO("reachable row window > 254 rows");
+        const int cells = (a.win_rows + 2) * c->n_actions[a.qi];
+        off = align_up((size_t)cells * esz, 16);
+        a.am_off = (int)off; off = align_up(off + a.win_rows + 2, 16);
+        a.g_off = (int)off; off = align_up(off + (size_t)tuples + 1, 16);
+        a.hist_off = (int)off; a.hist_dwords = (cells + 1) / 2; off = align_up(off + 4 * (size_t)a.hist_dwords, 16);
+    }
+    a.cdf_off = (int)off;
+    if (a.n_r == 2) {
+        const size_t cdf = (size_t)2 * (npid + 1) * apad * 4;
+        if (cdf > 24 * 1024) NO("price grid too large for in-LDS policy tables");
+        off = align_up(off + cdf, 16);
+    }
+    a.logs_off = (int)off; off += 64 * 4 * 8;
+    a.game_lds_bytes = (int)align_up(off, 16);
+    a.qrows_off = (int)align_up((size_t)tuples * 2, 16);
+    a.xf_off = (int)align_up((size_t)a.qrows_off + (size_t)tuples * 2, 16);
+    a.aq_off = (int)align_up((size_t)a.xf_off + (size_t)npid * 4, 16);
+    a.lut_lds_bytes = a.aq_off + 2 * 128 * 8;
+    a.price_off = a.lut_lds_bytes;
+    if ((size_t)a.price_off + 8 * (size_t)tuples > kPTupleLutRegion - 64) NO("LUT image too large");
+    p.scratch_bytes = kPTupleLutRegion + (a.n_r == 1 ? (size_t)c->n_games * (size_t)(npid + 1) * apad * 4 : 0);
+    const DevInfo dv = dev_info();
+    const int cap_waves = a.n_r == 1 ? 12 : 16;                     // compiled for 3 / 4 waves per SIMD
+    int best_w = 0, best_total = 0, best_b = 0;
+    for (int w = 1; w <= 8; w++) {
+        const int lds = a.lut_lds_bytes + w * a.game_lds_bytes;
+        if (lds > dv.lds_per_cu) break;
+        int b = dv.lds_per_cu / (((lds + 511) / 512) * 512);
+        if (b * w > cap_waves) b = cap_waves / w;
+        if (b < 1) continue;
+        const int total = b * w;
+        const bool even = (w & 3) == 0, best_even = best_w > 0 && (best_w & 3) == 0;
+        if (total > best_total || (total == best_total && ((even && !best_even) || (even == best_even && w < best_w)))) {
+            best_total = total; best_w = w; best_b = b;
+        }
+    }
+    if (best_w == 0) NO("one game does not fit LDS");
+    p.waves_per_block = best_w; p.blocks_per_cu = best_b;
+    p.ok = true;
+    return p;
+#undef NO
+}
+
 int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* counter, double* state, thrl_run* run,
                         double* game_reward_log, double* game_action_log, void* stream) {
     int rc = validate(c);
@@ -904,6 +1020,7 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
         return fail(THRL_ERR_NULL, "a required pointer is NULL");
     if (run->n_episodes < 0) return fail(THRL_ERR_BAD_CONFIG, "n_episodes < 0");
     if (run->n_episodes == 0) return THRL_OK;
+    run->kernel_used = 0;                          // THRL_KERNEL_TUPLE when the tuple-chain kernel ran
     MixedArgs a;
     memset(&a, 0, sizeof(a));
     a.G = c->n_games; a.N = c->n_agents; a.T = c->max_steps; a.n_episodes = run->n_episodes;
@@ -934,11 +1051,50 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
         return fail(THRL_ERR_BAD_CONFIG, "sweep_noise_prob needs cfg.noise_prob > 0 (it switches the noise draws on)");
     a.sw_gamma = mx->sweep_gamma; a.sw_alpha = mx->sweep_alpha; a.sw_eps_end = mx->sweep_eps_end;
     a.sw_eps_step = mx->sweep_eps_step; a.sw_eps = mx->sweep_eps; a.sw_noise_prob = mx->sweep_noise_prob;
+    // ---- two-agent games with discrete policies, noise-free: the tuple-chain kernel (thrl_ptuple.hip), same results
+    {
+        PTuplePlan tp = plan_ptuple(c, mx);
+        if (tp.ok && mx->policy_tab && mx->policy_tab_bytes >= tp.scratch_bytes && !(mx->flags & THRL_MIXED_NO_TUPLE_KERNEL)) {
+            PTupleArgs& t = tp.a;
+            t.G = c->n_games; t.n_episodes = run->n_episodes; t.stride = a.stride;
+            t.env = a.env;
+            for (int i = 0; i < 2; i++) {
+                t.ag[i] = a.ag[i];
+                t.nn_params[i] = a.nn_params[i]; t.nn_stride[i] = a.nn_stride[i];
+                t.buf_price[i] = a.buf_price[i]; t.buf_action[i] = a.buf_action[i]; t.buf_reward[i] = a.buf_reward[i];
+                t.buf_nprice[i] = a.buf_nprice[i]; t.buf_len[i] = a.buf_len[i]; t.count0[i] = a.count0[i];
+                t.eps0[i] = a.eps0[i];
+            }
+            t.q = q; t.counter = counter; t.state = state;
+            unsigned char* base = (unsigned char*)mx->policy_tab;
+            t.lut = base;
+            t.next_game = (int32_t*)(base + kPTupleLutRegion - 64);
+            t.policy_tab = (float*)(base + kPTupleLutRegion);
+            t.game_reward_log = game_reward_log; t.game_action_log = game_action_log;
+            t.seed = run->seed; t.game_offset = run->game_offset; t.first_episode = run->first_episode;
+            t.waves_per_block = tp.waves_per_block;
+            int grid = (c->n_games + tp.waves_per_block - 1) / tp.waves_per_block;
+            const int max_grid = dev_info().cus * tp.blocks_per_cu;
+            if (grid > max_grid) grid = max_grid;
+            const size_t lds = (size_t)t.lut_lds_bytes + (size_t)tp.waves_per_block * t.game_lds_bytes;
+            hipStream_t s = (hipStream_t)stream;
+            int e = launch_ptuple_lut(t, base, s);
+            if (e) return hip_fail(e, "k_ptuple_lut launch");
+            if (hipMemsetAsync(t.next_game, 0, sizeof(int32_t), s) != hipSuccess) return hip_fail((int)hipGetLastError(), "hipMemsetAsync");
+            e = launch_ptuple(t, c->q_dtype, grid, tp.waves_per_block * 64, lds, s);
+            if (e) return hip_fail(e, "k_ptuple_episodes launch");
+            run->kernel_used = THRL_KERNEL_TUPLE;
+            goto bookkeeping;
+        }
+    }
     a.policy_tab = mx->policy_tab; a.policy_tab_bytes = mx->policy_tab ? mx->policy_tab_bytes : 0;
+    {
     const char* why = "";
     if (plan_mixed(a, c->q_dtype, &why)) return fail(THRL_ERR_UNSUPPORTED, "thrl_mixed_episodes: %s", why);
     const int e = launch_mixed(a, c->q_dtype, (hipStream_t)stream);
     if (e) return hip_fail(e, "k_mixed_episodes launch");
+    }
+bookkeeping:
     // host mirror of the bookkeeping that is identical for every game
     for (int ep = 0; ep < run->n_episodes; ep++)
         for (int i = 0; i < c->n_agents; i++) {
@@ -968,8 +1124,15 @@ size_t thrl_mixed_policy_table_bytes(const thrl_cfg* c, const thrl_mixed* mx) {
         a.kind[i] = mx->kind[i];
     }
     const char* why = "";
-    if (plan_mixed(a, c->q_dtype, &why)) return 0;
-    return a.ptab_tuples > 0 ? a.ptab_need_bytes : 0;
+    size_t need = 0;
+    if (plan_mixed(a, c->q_dtype, &why) == 0 && a.ptab_tuples > 0) need = a.ptab_need_bytes;
+    // the tuple-chain kernel keeps its LUT image (and, against a QTable, its CDF rows) in the same scratch; buffer
+    // state (count) does not change the size
+    thrl_mixed probe = *mx;
+    for (int i = 0; i < c->n_agents && i < THRL_MAXA; i++) probe.count[i] = 0;
+    const PTuplePlan tp = plan_ptuple(c, &probe);
+    if (tp.ok && tp.scratch_bytes > need) need = tp.scratch_bytes;
+    return need;
 }
 
 int thrl_cac_init(int n_games, float* params, uint64_t seed, uint64_t game_offset, int agent, void* stream) {

@@ -110,6 +110,32 @@ int launch_tuple(const TupleArgs& a, int q_dtype, int grid, int block, size_t ld
 int launch_tuple_f32(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_tuple_f64(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 
+// ---- two-agent games with discrete neural-policy agents on the tuple-chain design (thrl_ptuple.hip)
+struct PTupleArgs {
+    int32_t G, T, n_episodes, tuples, npid;
+    int32_t kind[2];                // 0 = QTable, 1 = Reinforce, 2 = ActorCritic
+    int32_t qi, n_r, ri[2];         // the QTable agent (or -1), the policy agents
+    int32_t waves_per_block, lut_lds_bytes, game_lds_bytes;
+    int32_t qrows_off, xf_off, aq_off, price_off;        // byte offsets in the LUT image (price: HBM only)
+    int32_t am_off, g_off, hist_off, hist_dwords, cdf_off, logs_off;      // byte offsets in the per-game LDS region
+    int32_t row_lo, win_rows;       // the QTable agent's row window
+    int64_t stride;
+    EnvParams env;
+    AgentParams ag[2];
+    void* q; int32_t* counter; double* state;
+    const unsigned char* lut;
+    const float* nn_params[2]; int32_t nn_stride[2];
+    double* buf_price[2]; int32_t* buf_action[2]; double* buf_reward[2]; double* buf_nprice[2];
+    int32_t buf_len[2], count0[2];
+    double eps0[2];
+    float* policy_tab;              // HBM CDF rows [G][npid + 1][APAD] (one policy against a QTable)
+    double* game_reward_log; double* game_action_log;    // [n_episodes][2][G]
+    int32_t* next_game;
+    uint64_t seed, game_offset, first_episode;
+};
+int launch_ptuple_lut(const PTupleArgs& a, unsigned char* out, hipStream_t s);
+int launch_ptuple(const PTupleArgs& a, int q_dtype, int grid, int block, size_t lds_bytes, hipStream_t s);
+
 int launch_generic(const GenericArgs& a, int q_dtype, hipStream_t s);
 int launch_finalize_logs(double* sum_reward, double* sum_action, int n, int G, hipStream_t s);
 int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s);

@@ -103,6 +103,8 @@ class MixedGameBatch:
                                 "the device update kernel takes at most %d" % (self.kinds[i], i, n_train,
                                                                                 self.min_memory[i], self.T, limit))
         self.policy_table = True             # False: the fused kernel evaluates the policy at every step (same results)
+        self.tuple_kernel = True             # False: keep the general fused kernel where the tuple-chain one applies (same results)
+        self.last_episode_kernel = None
         self._ptab = None
         self.count = [0] * self.N            # appends since the last empty()
         self.episode = 0
@@ -376,6 +378,8 @@ class MixedGameBatch:
                         self._ptab = torch.empty((max(need, 4) // 4,), dtype=torch.float32, device=self.device) if need else False
                     if self._ptab is not False:
                         mx.policy_tab, mx.policy_tab_bytes = self._ptab.data_ptr(), self._ptab.numel() * 4
+                if not self.tuple_kernel:
+                    mx.flags = 1                       # THRL_MIXED_NO_TUPLE_KERNEL
                 r = _lib.Run()
                 r.seed, r.game_offset, r.first_episode, r.n_episodes = self.seed, self.game_offset, self.episode, k
                 for i in range(N):
@@ -385,6 +389,7 @@ class MixedGameBatch:
                                                       self._p(rlog[base:]), self._p(alog[base:]), self._stream()),
                            "thrl_mixed_episodes")
                 self._fused_launched = True
+                self.last_episode_kernel = "tuple" if r.kernel_used == _lib.KERNEL_TUPLE else "wave"
                 rmean[done:done + k] = rlog[base:base + k].mean(dim=2)
                 amean[done:done + k] = alog[base:base + k].mean(dim=2)
                 self.eps = [r.eps[i] for i in range(N)] + self.eps[N:]
@@ -398,7 +403,8 @@ class MixedGameBatch:
                             self.nn[i].train(b["price"], b["action"], b["reward"], next_price=b["nprice"], rows=True)
                             self.count[i] = 0
             torch.cuda.synchronize(self.device)
-            out = dict(kernel="mixed-fused", reward_log=rmean.cpu().numpy(), action_log=amean.cpu().numpy())
+            out = dict(kernel="mixed-fused", episode_kernel=self.last_episode_kernel, reward_log=rmean.cpu().numpy(),
+                       action_log=amean.cpu().numpy())
             if per_game_logs:
                 out.update(game_reward_log=rlog.cpu().numpy(), game_action_log=alog.cpu().numpy())
         return out
