@@ -54,7 +54,7 @@ VALU_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector
 NN_HIDDEN = 256
 N_SIMD, N_CU = 1024, 256            # MI355X: 256 CUs x 4 SIMD-32
 KEY_WAVE = "k_wave_episodes<float,2,1> (headline)"
-KEY_MIXED = {"rr": "k_mixed_wave<float,NR=2,24,2,memo> (2 x Reinforce)", "qr": "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)"}
+KEY_MIXED = {"rr": "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)", "qr": "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"}
 
 
 def library_info():
@@ -209,7 +209,7 @@ def nn_roofline(agents, env_steps, gpu_s, lib):
     only: the policy memo and the state folding SKIP work, and skipped work is not counted."""
     nt = (_load_json("nn_traffic.json") or {}).get("pairings", {}).get(agents)
     pr = issue_price(KEY_MIXED.get(agents, ""))
-    out = {"bound": "valu_issue", "kernel": "k_mixed_wave + k_nn_reinforce_train (whole step)", "unit": "Ginst/s",
+    out = {"bound": "valu_issue", "kernel": "k_ptuple_episodes + k_nn_reinforce_train (whole step)", "unit": "Ginst/s",
            "achieved": None, "peak": None, "frac": None, "traffic": None, "gpu_time_ms": gpu_s * 1e3}
     if not nt or not pr:
         out["note"] = "no PMC summary for this pairing in profiles/nn_traffic.json: only the time is measured here"

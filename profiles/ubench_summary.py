@@ -49,7 +49,7 @@ def main():
         if not fs:
             continue
         disp = collections.OrderedDict()
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):      # (a pass collected twice leaves two files: the newest counts)
             disp.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
         ks = sorted(disp)
         n_cls = len(ks) // (2 * len(WS))
