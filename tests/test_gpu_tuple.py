@@ -157,3 +157,46 @@ def test_tuple_equals_generic_at_65536_games_three_players(dtype):
     half = _batch(THREE, 1000, dtype=dtype, kernel="tuple", seed=5, game_offset=30000).init_tables()
     half.run(E)
     assert torch.equal(half.q, a.q[30000:31000]) and torch.equal(half.counter, a.counter[30000:31000])
+
+
+def _random_tuple_config(rs):
+    """A random configuration the tuple-chain kernel must take: 1-4 agents, individual grids, no noise, buffers that train
+    once per episode, <= 4,096 action tuples."""
+    while True:
+        n = int(rs.choice([1, 2, 3, 3, 4]))
+        T = int(rs.choice([1, 7, 25, 64, 65, 100, 129, 200]))
+        acts = [int(rs.choice([2, 3, 5, 8, 11, 16, 17, 21, 33, 40])) for _ in range(n)]
+        if int(np.prod(acts)) <= 4096:
+            break
+    agents = []
+    for i in range(n):
+        lo = float(np.round(rs.uniform(0.0, 0.3), 2))
+        agents.append(dict(name="QTable", gamma=float(rs.choice([0.35, 0.9, 0.95, 0.99])), actions=acts[i],
+                           states=int(rs.choice([4, 16, 50, 100, 200])), alpha=float(rs.choice([0.05, 0.1, 0.5])),
+                           eps_end=float(rs.choice([0.0, 0.001, 0.05])), epsilon=float(rs.choice([0.0, 0.05, 0.5, 1.0])), eps_step=0.99,
+                           action_range=[lo, float(np.round(lo + rs.uniform(0.02, 0.6 / n), 2))],
+                           max_state=float(rs.choice([10, 10, 12])), min_memory=int(rs.choice([0, 1, max(1, T // 2), T])),
+                           capacity=int(rs.choice([T, T + 3, 500]))))
+    return {"agents": agents, "environment": dict(name="NoisyPriceState", noise_prob=0.0, a=10, b=1, nplayers=n, max_steps=T)}
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_tuple_kernel_fuzz_vs_oracle(case):
+    rs = np.random.RandomState(7000 + case)
+    config = _random_tuple_config(rs)
+    dtype = "float64" if case % 3 == 0 else "float32"
+    G, E = int(rs.randint(1, 70)), int(rs.choice([1, 3, 9, 35]))
+    if config["environment"]["max_steps"] * G * E > 400000:
+        E = 3
+    seed, off = int(rs.randint(0, 10 ** 6)), int(rs.randint(0, 1 << 33))
+    gb = _batch(config, G, dtype=dtype, kernel="auto", seed=seed, game_offset=off).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    label = "%s %s G=%d E=%d -> %s" % (json.dumps(config)[:300], dtype, G, E, out["kernel"])
+    two_same = len(config["agents"]) == 2 and all(config["agents"][0][k] == config["agents"][1][k] for k in ("actions", "states", "max_state"))
+    assert out["kernel"] == ("wave" if two_same and config["agents"][0]["actions"] <= 32 else "tuple"), label
+    q, c, s, eps, oo = _oracle(config, G, dtype, q0, s0, E, seed=seed, game_offset=off)
+    assert np.array_equal(gb.tables_numpy(), q), label
+    assert np.array_equal(gb.counters_numpy(), c) and np.array_equal(gb.states_numpy(), s), label
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12, atol=1e-13, err_msg=label)
+    np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13, err_msg=label)

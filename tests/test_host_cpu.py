@@ -444,3 +444,27 @@ def test_oracle_golden_under_sanitizers():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+
+
+def test_kernel_selection_covers_individual_grids_on_the_host(lib):
+    """thrl_select_kernel / thrl_workspace_bytes (host logic, no GPU): two agents on one grid -> the wave kernel; 1-4 agents with
+    individual grids in a noise-free game that trains once per episode -> the tuple-chain kernel; noise, buffers that span
+    episodes, five agents or too many action tuples -> the generic kernel."""
+    from th_rl_amd import _lib
+    def sel(agents, **env):
+        conf = {"agents": agents, "environment": dict(CFG_ENV, nplayers=len(agents), **env)}
+        cfg, _ = _lib.cfg_from_config(conf, 4096, 0)
+        return _lib.KERNEL_NAMES[lib.thrl_select_kernel(ctypes.byref(cfg), 0)], lib.thrl_workspace_bytes(ctypes.byref(cfg))
+    a21 = dict(CFG_AGENT)
+    a11 = dict(CFG_AGENT, actions=11, states=50, action_range=[0.1, 0.3], min_memory=25)
+    a5 = dict(CFG_AGENT, actions=5, states=20, action_range=[0.0, 0.3], min_memory=25)
+    assert sel([a21, a21])[0] == "wave"
+    k, ws = sel([a11, dict(a21, min_memory=25), a5], max_steps=25)
+    assert k == "tuple" and ws == 160 * 1024
+    assert sel([a11, dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                 # two agents, different grids
+    assert sel([dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                     # one agent
+    assert sel([a11, dict(a21, min_memory=25), a5], max_steps=25, noise_prob=0.05)[0] == "generic"
+    assert sel([a11, dict(a21, min_memory=25), a5], max_steps=10)[0] == "generic"           # buffers fill every 3rd episode
+    assert sel([a5] * 5, max_steps=25)[0] == "generic"                                      # five agents
+    assert sel([a21, a21, dict(a21, action_range=[0.0, 0.1])], max_steps=100)[0] == "generic"   # 9,261 action tuples
+    assert b"tuples" in lib.thrl_last_error() or b"tuple" in lib.thrl_last_error()

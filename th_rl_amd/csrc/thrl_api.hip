@@ -219,6 +219,7 @@ WavePlan plan_wave(const thrl_cfg* c, const thrl_run* run, bool injected) {
     const WaveLut L = wave_lut_layout(A);
     p.lut_bytes = L.lds_bytes;          // LDS-staged part of the LUT image
     p.game_lds_bytes = 2 * (p.win_rows + 2) * A * (c->q_dtype == 1 ? 8 : 4);
+    if (c->q_dtype == 0 && !(c->noise_prob > 0.0)) p.game_lds_bytes += 256;       // per-step words of half a segment (thrl_wave_kernel.h kLdsMK)
     // choose waves/block to maximise resident waves per CU (LDS-bound); a block may take the whole CU's LDS
     int best_w = 0, best_total = 0, best_b = 0;
     const DevInfo dv = dev_info();

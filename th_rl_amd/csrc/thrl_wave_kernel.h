@@ -576,6 +576,9 @@ k_wave_episodes(const WaveArgs a) {
     // re-read the row's last rdn columns), rdn = 2 / 3 / 4 for A = 2 / <= 24 / <= 32
     const int rdn = A < 3 ? 2 : (A <= 24 ? 3 : 4);
     const unsigned rd_base = (half ? tab1_off : tab0_off) + (unsigned)sizeof(QT) * (unsigned)min(rdn * jj, A - rdn);
+    // 256 bytes behind the wave's tables (float32, noise-free configurations: thrl_api.hip plan_wave): per-step words of a segment
+    constexpr bool kLdsMK = sizeof(QT) == 4 && !NOISE && !GREEDY && NRSEG == 1 && !(kAblate & 6);
+    const unsigned mk_addr = tab0_off + 2u * (unsigned)((W + 2) * A) * (unsigned)sizeof(QT);
 
     const AgentParams& p0 = a.ag[0];
     const AgentParams& p1 = a.ag[1];
@@ -851,7 +854,34 @@ k_wave_episodes(const WaveArgs a) {
                 };
                 // the tables of group g+1 are built (their gathers in flight) while group g's chain runs
                 uint32_t ta[4][NRSEG], tb[4][NRSEG];
+                // float32 plain variants: the two per-step words reach the lanes as VGPRs through a uniform-address LDS read
+                // issued ONE GROUP AHEAD, so the table build runs in the fast issue class (all-VGPR v_and / v_add: 2.3 cycles per
+                // instruction per SIMD against 4.1 with an SGPR operand, and no v_readlane: profiles/r03_ubench_issue.md)
+                v2u mkr[4] = {v2u{0u, 0u}, v2u{0u, 0u}, v2u{0u, 0u}, v2u{0u, 0u}};
+                // (256 bytes per wave hold 32 steps: lanes 0-31 write theirs before the first group, lanes 32-63 overwrite them
+                //  when the build reaches step 28 -- every read of steps 0-31 has been issued by then and the LDS runs a wave's
+                //  operations in order)
+                if (kLdsMK) {
+                    if (lane < 32) lds_store<v2u>(mk_addr + 8u * (unsigned)lane, v2u{Mv, Kv});
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) mkr[j] = lds_load<v2u>(mk_addr + 8u * (unsigned)j);
+                }
                 auto build4 = [&](int t0, uint32_t (&tab)[4][NRSEG]) {
+                    if (kLdsMK) {
+                        unsigned ad[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) ad[j] = halves_sum(R[0] & mkr[j].x) + mkr[j].y;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) tab[j][0] = lds_load<unsigned short>(ad[j]);
+                        if (t0 == 28) {
+                            if (lane >= 32) lds_store<v2u>(mk_addr + 8u * (unsigned)(lane - 32), v2u{Mv, Kv});
+                            __builtin_amdgcn_wave_barrier();
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) mkr[j] = lds_load<v2u>(mk_addr + 8u * (unsigned)(min(t0 + 4 + j, 63) & 31));
+                        return;
+                    }
                     // one scalar test per group of four steps: a group without a noisy step (81 % of them at
                     // noise_prob 0.05) takes the straight-line path
                     if (NOISE && ((noisy_steps >> t0) & 0xFull)) {
