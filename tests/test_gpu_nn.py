@@ -693,6 +693,8 @@ def test_full_size_properties_65536_games_neural(pair):
     ("q_vs_reinforce", [dict(Q_AGENT, min_memory=30, capacity=64), dict(R_AGENT, min_memory=70, entropy=0.01)], 30),
     ("reinforce_vs_q", [dict(R_AGENT, min_memory=50), dict(Q_AGENT, min_memory=25, capacity=500, actions=15)], 25),
     ("two_reinforce", [dict(R_AGENT, min_memory=60, entropy=0.02), dict(R_AGENT, min_memory=35)], 20),
+    ("reinforce_ring_wraps", [dict(Q_AGENT, min_memory=25, capacity=40), dict(R_AGENT, min_memory=60, capacity=70)], 25),
+    ("two_reinforce_rings_wrap_T64", [dict(R_AGENT, min_memory=150, capacity=170), dict(R_AGENT, min_memory=100, capacity=128)], 64),
     ("q_vs_actorcritic_T70", [dict(Q_AGENT, min_memory=70), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
                                                              "action_range": [0.2, 0.4], "min_memory": 140}], 70),
     ("reinforce_vs_actorcritic", [dict(R_AGENT, min_memory=60), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
