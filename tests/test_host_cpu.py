@@ -468,3 +468,24 @@ def test_kernel_selection_covers_individual_grids_on_the_host(lib):
     assert sel([a5] * 5, max_steps=25)[0] == "generic"                                      # five agents
     assert sel([a21, a21, dict(a21, action_range=[0.0, 0.1])], max_steps=100)[0] == "generic"   # 9,261 action tuples
     assert b"tuples" in lib.thrl_last_error() or b"tuple" in lib.thrl_last_error()
+
+
+def test_policy_table_scratch_is_sized_on_the_host(lib):
+    """thrl_mixed_policy_table_bytes (host logic): QTable vs Reinforce on the 21 x 21 grid -> LUT region + 442 CDF rows per game
+    for the tuple-chain kernel; two Reinforce agents on one grid -> the LUT region only (their tables live in LDS); a continuous
+    agent in the game -> nothing."""
+    from th_rl_amd import _lib
+    q = dict(CFG_AGENT)
+    r = dict(name="QTable", states=1, actions=21, action_range=[0.2, 0.4], capacity=1, min_memory=1)     # placeholder slot of a neural agent
+    G = 1000
+    def need(kinds, agents, buf_len, mm):
+        cfg, _ = _lib.cfg_from_config({"agents": agents, "environment": dict(CFG_ENV)}, G, 0)
+        mx = _lib.Mixed()
+        for i, k in enumerate(kinds):
+            mx.kind[i] = k; mx.buf_len[i] = buf_len[i]; mx.min_memory[i] = mm[i]
+        return int(lib.thrl_mixed_policy_table_bytes(ctypes.byref(cfg), ctypes.byref(mx)))
+    qr = need([0, 1], [q, r], [200, 1100], [100, 1000])
+    assert qr == 64 * 1024 + G * 442 * 24 * 4
+    rr = need([1, 1], [r, r], [1100, 1100], [1000, 1000])
+    assert rr == 64 * 1024
+    assert need([0, 3], [q, dict(r, actions=2)], [200, 1100], [100, 1000]) == 0

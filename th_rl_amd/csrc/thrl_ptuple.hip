@@ -280,6 +280,8 @@ k_ptuple_episodes(const PTupleArgs a) {
                     const uint32_t cell = valid ? srow * (uint32_t)Aq + act : 0u;
                     ops[seg].set(tab[cell], rew[qi], tcq);
                     word[seg] = ns | (cell << 8);
+                    if (valid && a.counter)
+                        __hip_atomic_fetch_add(&hist[cell >> 1], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
                 // logs: reward / T and scaled / T of this segment's steps (trainer.py:65-66), summed in step order below
                 if (valid) {
@@ -315,7 +317,7 @@ k_ptuple_episodes(const PTupleArgs a) {
                         Ops<QT> xo = ops[seg];
                         xo.gather(sel, ops[seg], true);
                         const int nb = min(16, T - base_t);
-                        const bool cntr = a.counter != nullptr;
+                        const bool cntr = false;                  // (counted lane-parallel in phase (e))
 #define THRL_PT_STEP(J) if ((J) < nb) tup::replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cntr, ag_q, alpha_q, gamma_q);
                         THRL_PT_STEP(0) THRL_PT_STEP(1) THRL_PT_STEP(2) THRL_PT_STEP(3) THRL_PT_STEP(4) THRL_PT_STEP(5) THRL_PT_STEP(6) THRL_PT_STEP(7)
                         THRL_PT_STEP(8) THRL_PT_STEP(9) THRL_PT_STEP(10) THRL_PT_STEP(11) THRL_PT_STEP(12) THRL_PT_STEP(13) THRL_PT_STEP(14) THRL_PT_STEP(15)

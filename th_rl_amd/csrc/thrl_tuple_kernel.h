@@ -369,6 +369,10 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     ops[seg][i].set(ov, re, td_coef(p));
                     word[seg][i] = ns | (cell << 8);
                     if (valid) { lr[i] += re; la[i] += lut_sct[i * 64 + act]; }
+                    // visit counter of the transition (agents.py:76), lane-parallel (the replay keeps only what is serial)
+                    if (valid && a.counter)
+                        __hip_atomic_fetch_add(&hist[a.hist_off_i[i] + (cell >> 1)], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -390,7 +394,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         xo.gather(sel, ops[seg][i], my_ag == i);
                     }
                     const int nb = min(16, T - base_t);
-                    const bool cnt = a.counter != nullptr;
+                    const bool cnt = false;                   // (counted lane-parallel in phase (e))
 #define THRL_TUP_STEP(J) if ((J) < nb) replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cnt, ag_me, alpha_me, gamma_me);
                     THRL_TUP_STEP(0) THRL_TUP_STEP(1) THRL_TUP_STEP(2) THRL_TUP_STEP(3) THRL_TUP_STEP(4) THRL_TUP_STEP(5) THRL_TUP_STEP(6) THRL_TUP_STEP(7)
                     THRL_TUP_STEP(8) THRL_TUP_STEP(9) THRL_TUP_STEP(10) THRL_TUP_STEP(11) THRL_TUP_STEP(12) THRL_TUP_STEP(13) THRL_TUP_STEP(14) THRL_TUP_STEP(15)
