@@ -114,16 +114,23 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     price += (size_t)g * ld; reward += (size_t)g * ld; action += (size_t)g * ld;
     if (AC) nprice += (size_t)g * ld;
 
-    for (int k = 0; k < A; k++) W2t[tid * kPad + k] = w[2 * kH + k * kH + tid];
-    for (int k = A; k < kPad; k++) W2t[tid * kPad + k] = 0.0f;
-    w1s[tid] = w[tid]; b1s[tid] = w[kH + tid];
-    if (tid < kMaxA) b2s[tid] = tid < A ? w[2 * kH + A * kH + tid] : 0.0f;
+    // The weights are staged behind the transitions: for Reinforce the serial return recurrence (one thread, ~25 % of the
+    // block's time) needs only the rewards, so waves 1-3 transpose the weights into LDS WHILE thread 0 runs it.
+    auto stage_weights = [&](int r0, int stride) {
+        for (int r = r0; r < kH; r += stride) {
+            for (int k = 0; k < A; k++) W2t[r * kPad + k] = w[2 * kH + k * kH + r];
+            for (int k = A; k < kPad; k++) W2t[r * kPad + k] = 0.0f;
+            w1s[r] = w[r]; b1s[r] = w[kH + r];
+            if (r < kMaxA) b2s[r] = r < A ? w[2 * kH + A * kH + r] : 0.0f;
+            if (AC) wvs[r] = w[Pp + r];
+        }
+    };
     for (int n = tid; n < NX; n += 256) {
         xs[n] = n < N ? (float)price[n] : 0.0f;
         Gs[n] = n < N ? (float)reward[n] : 0.0f;
         if (AC) xps[n] = n < N ? (float)nprice[n] : 0.0f;
     }
-    if (AC) wvs[tid] = w[Pp + tid];
+    if (AC) stage_weights(tid, 256);
     __syncthreads();
     float wva = 0.0f, wvb = 0.0f, gbv = 0.0f;
     int U = 0;                                              // > 0: passes run over U distinct states
@@ -135,16 +142,28 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
             float carry = Gs[N - 1];
             int n = N - 2;
             for (; n >= 0 && ((n + 1) & 3) != 0; n--) { carry = __fadd_rn(Gs[n], __fmul_rn(gamma, carry)); Gs[n] = carry; }
-#pragma unroll 4
-            for (; n >= 3; n -= 4) {
-                f4 q = *reinterpret_cast<const f4*>(Gs + n - 3);
+            auto quad = [&](f4& q) {
                 q.w = __fadd_rn(q.w, __fmul_rn(gamma, carry));
                 q.z = __fadd_rn(q.z, __fmul_rn(gamma, q.w));
                 q.y = __fadd_rn(q.y, __fmul_rn(gamma, q.z));
                 q.x = __fadd_rn(q.x, __fmul_rn(gamma, q.y));
                 carry = q.x;
+            };
+            // sixteen values per round trip: the four LDS reads are issued before the dependent chain starts
+            for (; n >= 15; n -= 16) {
+                f4 q0 = *reinterpret_cast<const f4*>(Gs + n - 3), q1 = *reinterpret_cast<const f4*>(Gs + n - 7);
+                f4 q2 = *reinterpret_cast<const f4*>(Gs + n - 11), q3 = *reinterpret_cast<const f4*>(Gs + n - 15);
+                quad(q0); quad(q1); quad(q2); quad(q3);
+                *reinterpret_cast<f4*>(Gs + n - 3) = q0; *reinterpret_cast<f4*>(Gs + n - 7) = q1;
+                *reinterpret_cast<f4*>(Gs + n - 11) = q2; *reinterpret_cast<f4*>(Gs + n - 15) = q3;
+            }
+            for (; n >= 3; n -= 4) {
+                f4 q = *reinterpret_cast<const f4*>(Gs + n - 3);
+                quad(q);
                 *reinterpret_cast<f4*>(Gs + n - 3) = q;
             }
+        } else if (tid >= 64) {
+            stage_weights(tid - 64, 192);
         }
         __syncthreads();
         float part = 0.0f;
@@ -472,7 +491,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     // Adam (torch.optim.Adam defaults, lr from the caller).  The gradient sits in the registers of the pass-B owners
     // (128 threads x 46 parameters); updating from there is 46 dependent HBM round trips per block -- the phase was
     // ~80 % of the kernel.  So it is staged in LDS and all 256 threads sweep the parameter vector in order:
-    // coalesced loads of m, v, w, eight per thread in flight, three round trips for the 5,909 parameters.
+    // coalesced loads of m, v, w, twelve per thread in flight, two round trips for the 5,909 parameters.
     const float t = (float)(step + 1);
     const float bc1 = 1.0f - powf(0.9f, t), bc2s = sqrtf(1.0f - powf(0.999f, t));
     const float step_size = lr / bc1;
@@ -491,7 +510,7 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     if (tid < A) gl[2 * kH + A * kH + tid] = gb2;
     if (AC && tid == 255) gl[Pp + kH] = gbv;
     __syncthreads();
-    constexpr int kB = 8;
+    constexpr int kB = 12;
     for (int i0 = tid; i0 < P; i0 += 256 * kB) {
         float mm[kB], vv[kB], ww[kB], gg[kB];
 #pragma unroll
