@@ -30,7 +30,8 @@ def collect(tag, kernel, last=0):
     return counters, geom
 
 def stats(tag, kernel):
-    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "*", "*_kernel_stats.csv"))):
+    # (a pass collected twice leaves two files, named by pid: the newest one counts)
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True):
         for r in csv.DictReader(open(f)):
             if kernel in r["Name"]:
                 return dict(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), min_ns=float(r["MinNs"]), max_ns=float(r["MaxNs"]))
