@@ -261,12 +261,15 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
  * at 1.0, one Adam step (lr, betas 0.9/0.999, eps 1e-8).  step = Adam step count BEFORE the call.
  * price / action / reward: device [G][ld], n <= ld valid entries per row (a replay ring of thrl_mixed can be
  * passed as it is: ld = buf_len).  sweep_gamma / sweep_entropy: device [G] per-game values (a config sweep as
- * one batch) or NULL for the scalars.  grad_out [G][P] (optional) receives the clipped gradient. */
+ * one batch) or NULL for the scalars.  grad_out [G][P] (optional) receives the clipped gradient.  returns_scratch
+ * (optional): device [G][ld] floats; when given, the discounted returns (:178-181: a serial recurrence per game) are computed
+ * by a pre-pass with one lane per game instead of by one thread of each game's block -- the same operations in the same
+ * order, so the same bits; NULL keeps the in-kernel form. */
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v,
                             int32_t step, int32_t n, int32_t ld, const double* price, const int32_t* action,
                             const double* reward, double gamma, double entropy_coef, double lr,
                             const double* sweep_gamma, const double* sweep_entropy,
-                            float* grad_out, void* stream);
+                            float* grad_out, float* returns_scratch, void* stream);
 /*
  * `ActorCritic` (agents.py:222-330): Reinforce's network plus a value head fc_v (256 -> 1, bias
  * initialised to 1000, :243-244) on the shared hidden layer.  Parameter vector per game,

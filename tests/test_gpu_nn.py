@@ -740,3 +740,28 @@ def test_policy_tuple_kernel_is_not_taken_with_noise_or_unfit_buffers():
     spans = MixedGameBatch({"agents": [dict(Q_AGENT, min_memory=60), dict(R_AGENT, min_memory=50)],
                             "environment": dict(ENV, max_steps=25)}, n_games=4, seed=1).init_tables()     # QTable trains every 3rd episode
     assert spans.run(2, fused=True)["episode_kernel"] == "wave"
+
+
+@pytest.mark.parametrize("n,G", [(1000, 200), (333, 65), (64, 130), (2, 64)])
+def test_returns_prepass_equals_in_kernel_recurrence(n, G):
+    """Reinforce.train_net's discounted returns (agents.py:178-181) by the pre-pass kernel (one lane per game, tiles transposed
+    through LDS) against the in-kernel form (one thread per block): same operations in the same order, so parameters, Adam
+    moments and clipped gradients are bit-identical -- with the scalar gamma and with a per-game gamma sweep, over two updates."""
+    from th_rl_amd.nn import ReinforceBatch
+    rs = np.random.RandomState(n + G)
+    price = rs.choice(np.round(np.linspace(2.0, 6.0, 41), 10), (n, G))
+    action = rs.randint(0, 21, (n, G)).astype(np.int32)
+    reward = rs.uniform(5.0, 12.5, (n, G))
+    for sweep in (False, True):
+        outs = []
+        for prepass in (True, False):
+            rb = ReinforceBatch(G, actions=21, gamma=0.995, entropy=0.01, seed=3).init()
+            rb.returns_prepass = prepass
+            if sweep:
+                rb.set_sweep(gamma=rs.__class__(5).choice([0.9, 0.98, 0.995], G))
+            g1 = rb.train(price, action, reward, want_grad=True).cpu().numpy().copy()
+            g2 = rb.train(price[::-1].copy(), action, reward[::-1].copy(), want_grad=True).cpu().numpy().copy()
+            outs.append((rb.params.cpu().numpy().copy(), rb.adam_m.cpu().numpy().copy(), rb.adam_v.cpu().numpy().copy(), g1, g2))
+        for x, y in zip(outs[0], outs[1]):
+            assert np.array_equal(x, y), (n, G, sweep)
+        assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][3]).max() > 0

@@ -158,7 +158,7 @@ def load():
     L.thrl_nn_act.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     L.thrl_nn_reinforce_train.restype = ctypes.c_int
     L.thrl_nn_reinforce_train.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, vp, i32, i32, i32, vp, vp, vp,
-                                          dbl, dbl, dbl, vp, vp, vp, vp]
+                                          dbl, dbl, dbl, vp, vp, vp, vp, vp]
     L.thrl_op_draws.restype = ctypes.c_int
     L.thrl_op_draws.argtypes = [cfgp, u64, u64, u64, i32, vp, vp, vp, vp, vp, vp]
     L.thrl_cac_init.restype = ctypes.c_int

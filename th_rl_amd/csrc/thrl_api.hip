@@ -864,7 +864,7 @@ int thrl_ac_train(int n_games, int n_actions, float* params, float* adam_m, floa
     if (nn_train_lds_bytes(n_actions, n, 1) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
     if (ld < n) return fail(THRL_ERR_BAD_CONFIG, "ld=%d < n=%d", ld, n);
     const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, ld, price, action, reward, next_price,
-                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
+                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out, nullptr,
                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train<AC> launch") : THRL_OK;
 }
@@ -882,7 +882,7 @@ int thrl_nn_act(int n_games, int n_actions, const float* params, const double* p
 int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* adam_m, float* adam_v, int32_t step,
                             int32_t n, int32_t ld, const double* price, const int32_t* action, const double* reward,
                             double gamma, double entropy_coef, double lr, const double* sweep_gamma,
-                            const double* sweep_entropy, float* grad_out, void* stream) {
+                            const double* sweep_entropy, float* grad_out, float* returns_scratch, void* stream) {
     int rc = nn_check(n_games, n_actions);
     if (rc) return rc;
     if (!params || !adam_m || !adam_v || !price || !action || !reward) return fail(THRL_ERR_NULL, "a required pointer is NULL");
@@ -892,7 +892,7 @@ int thrl_nn_reinforce_train(int n_games, int n_actions, float* params, float* ad
     if (nn_train_lds_bytes(n_actions, n, 0) > 160 * 1024) return fail(THRL_ERR_UNSUPPORTED, "transition buffer does not fit LDS");
     if (ld < n) return fail(THRL_ERR_BAD_CONFIG, "ld=%d < n=%d", ld, n);
     const int e = launch_nn_train(n_games, n_actions, params, adam_m, adam_v, step, n, ld, price, action, reward, nullptr,
-                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out,
+                                  (float)gamma, (float)entropy_coef, (float)lr, sweep_gamma, sweep_entropy, grad_out, returns_scratch,
                                   (hipStream_t)stream);
     return e ? hip_fail(e, "k_nn_reinforce_train launch") : THRL_OK;
 }

@@ -239,6 +239,7 @@ int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, i
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
                     const double* gamma_g, const double* ent_g,      // per-game gamma / entropy coefficient [G] or null
                     float* grad,
+                    float* returns_scratch,                            // [G][ld] floats or null (Reinforce: returns by a pre-pass)
                     hipStream_t s);
 // ---- continuous actor-critic agent CAC (thrl_cac.hip)
 int launch_cac_init(int G, float* params, uint64_t seed, uint64_t off, int agent, hipStream_t s);

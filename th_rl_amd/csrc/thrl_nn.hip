@@ -82,7 +82,8 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N, int ld,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
         const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
-        const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out) {
+        const double* __restrict__ gamma_g, const double* __restrict__ ent_g, float* __restrict__ grad_out,
+        const float* __restrict__ returns) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_nn[];
     if (gamma_g) gamma = (float)gamma_g[blockIdx.x];        // per-game sweeps (main.py:13-21 as one batch)
     if (ent_g) ent_coef = (float)ent_g[blockIdx.x];
@@ -113,6 +114,8 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     // the replayed transitions of game g: one contiguous row [ld] per array (game-major rings, ABI v3)
     price += (size_t)g * ld; reward += (size_t)g * ld; action += (size_t)g * ld;
     if (AC) nprice += (size_t)g * ld;
+    const bool have_returns = !AC && returns != nullptr;          // discounted returns computed by k_nn_returns (same bits)
+    if (have_returns) returns += (size_t)g * ld;
 
     // The weights are staged behind the transitions: for Reinforce the serial return recurrence (one thread, ~25 % of the
     // block's time) needs only the rewards, so waves 1-3 transpose the weights into LDS WHILE thread 0 runs it.
@@ -127,10 +130,10 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     };
     for (int n = tid; n < NX; n += 256) {
         xs[n] = n < N ? (float)price[n] : 0.0f;
-        Gs[n] = n < N ? (float)reward[n] : 0.0f;
+        Gs[n] = n < N ? (have_returns ? returns[n] : (float)reward[n]) : 0.0f;
         if (AC) xps[n] = n < N ? (float)nprice[n] : 0.0f;
     }
-    if (AC) stage_weights(tid, 256);
+    if (AC || have_returns) stage_weights(tid, 256);
     __syncthreads();
     float wva = 0.0f, wvb = 0.0f, gbv = 0.0f;
     int U = 0;                                              // > 0: passes run over U distinct states
@@ -138,7 +141,9 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         // discounted return: the reference's serial recurrence, last to first (agents.py:178-181)
         // One thread, the same operations in the same order; the chain runs in registers on aligned quads, so the
         // LDS reads of the next quads are in flight while the current one is computed (+1.7 % on 2 x Reinforce).
-        if (tid == 0) {
+        if (have_returns) {
+            // (nothing: Gs already holds the returns)
+        } else if (tid == 0) {
             float carry = Gs[N - 1];
             int n = N - 2;
             for (; n >= 0 && ((n + 1) & 3) != 0; n--) { carry = __fadd_rn(Gs[n], __fmul_rn(gamma, carry)); Gs[n] = carry; }
@@ -533,6 +538,45 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     }
 }
 
+// Discounted returns of Reinforce.train_net (agents.py:178-181) for G games, ONE LANE PER GAME: the recurrence
+// R_n = r_n + gamma * R_(n+1) must round its product and its sum separately, as the reference does, so it is a serial chain of
+// 2 N dependent operations per game -- a quarter of the update kernel's block time when one thread of a 256-thread block runs
+// it (profiles/exp_train_stamps.py), nothing when 64 games run it side by side.  A wave takes 64 games; tiles of 64
+// transitions are read coalesced (a game's ring row is contiguous), transposed through LDS, chained lane = game from the last
+// tile to the first, and written back coalesced as float32.  Same operations in the same order as the in-kernel form.
+__global__ void __launch_bounds__(64) k_nn_returns(int G, int N, int ld, const double* __restrict__ reward, float gamma,
+                                                    const double* __restrict__ gamma_g, float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x, g0 = blockIdx.x * 64;
+    const int gme = min(g0 + lane, G - 1);
+    const float gam = gamma_g ? (float)gamma_g[gme] : gamma;
+    float carry = 0.0f;
+    bool first = true;
+    for (int n0 = (N - 1) / 64 * 64; n0 >= 0; n0 -= 64) {
+        const int cols = min(64, N - n0);
+        for (int r0 = 0; r0 < 64; r0 += 16) {               // row r = game g0 + r, lane = transition n0 + lane
+            double v[16];                                   // sixteen row loads in flight per round trip
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = reward[(size_t)min(g0 + r0 + u, G - 1) * ld + n0 + min(lane, cols - 1)];
+#pragma unroll
+            for (int u = 0; u < 16; u++) tile[r0 + u][lane] = (float)v[u];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int c = cols - 1; c >= 0; c--) {               // lane = game
+            float v = tile[lane][c];
+            if (!first) v = __fadd_rn(v, __fmul_rn(gam, carry));
+            first = false;
+            carry = v;
+            tile[lane][c] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 64; r++)
+            if (g0 + r < G && lane < cols) out[(size_t)(g0 + r) * ld + n0 + lane] = tile[r][lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Philox draws of one lockstep step (same counters as the episode kernels)
 __global__ void __launch_bounds__(256) k_op_draws(int G, int N, uint64_t seed, uint64_t game_offset,
         uint32_t episode, uint32_t step, double env_a, double noise_lo, int32_t nA0, int32_t nA1, int32_t nA2,
@@ -582,14 +626,19 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
 }
 int launch_nn_train(int G, int A, float* params, float* m, float* v, int step, int N, int ld, const double* price,
                     const int32_t* action, const double* reward, const double* nprice, float gamma, float ent, float lr,
-                    const double* gamma_g, const double* ent_g, float* grad, hipStream_t s) {
+                    const double* gamma_g, const double* ent_g, float* grad, float* returns_scratch, hipStream_t s) {
     const size_t lds = nn_train_lds_bytes(A, N, nprice != nullptr);
+    if (returns_scratch && !nprice) {
+        hipLaunchKernelGGL(k_nn_returns, dim3((G + 63) / 64), dim3(64), 0, s, G, N, ld, reward, gamma, gamma_g, returns_scratch);
+        const hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return (int)e0;
+    }
     auto kern = nprice ? (A <= 24 ? k_nn_reinforce_train<24, true> : k_nn_reinforce_train<32, true>)
                        : (A <= 24 ? k_nn_reinforce_train<24, false> : k_nn_reinforce_train<32, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(G), dim3(256), lds, s, G, A, params, m, v, step, N, ld, price, action, reward, nprice,
-                       gamma, ent, lr, gamma_g, ent_g, grad);
+                       gamma, ent, lr, gamma_g, ent_g, grad, nprice ? nullptr : returns_scratch);
     return (int)hipGetLastError();
 }
 int launch_op_draws(int G, int N, uint64_t seed, uint64_t off, uint32_t episode, uint32_t step, double env_a,

@@ -31,6 +31,7 @@ class ReinforceBatch:
             self.adam_v = torch.zeros_like(self.params)
         self.step = 0
         self.gamma_g = self.entropy_g = None      # per-game sweeps (device float64 [G]) or None
+        self.returns_prepass = True               # False: the update kernel computes the returns itself (same results)
 
     def set_sweep(self, gamma=None, entropy=None):
         """Per-game gamma / entropy coefficient (arrays of length G): a config sweep as one batch."""
@@ -112,11 +113,18 @@ class ReinforceBatch:
             if not (ld == lda == ldr):
                 raise ThrlError("price / action / reward rows must share one pitch")
             grad = torch.zeros_like(self.params) if want_grad else None
+            # scratch for the returns pre-pass (one lane per game instead of one thread per block: same bits), kept
+            scr = None
+            if self.returns_prepass and self.G >= 64:
+                need = self.G * ld
+                if getattr(self, "_ret_scratch", None) is None or self._ret_scratch.numel() < need:
+                    self._ret_scratch = torch.empty((need,), dtype=torch.float32, device=self.device)
+                scr = self._ret_scratch
             _lib.check(self.L.thrl_nn_reinforce_train(self.G, self.A, self._p(self.params), self._p(self.adam_m),
                                                       self._p(self.adam_v), self.step, n, ld, self._p(d_p), self._p(d_a),
                                                       self._p(d_r), self.gamma, self.entropy, self.lr,
                                                       self._p(self.gamma_g), self._p(self.entropy_g),
-                                                      self._p(grad), self._stream()), "thrl_nn_reinforce_train")
+                                                      self._p(grad), self._p(scr), self._stream()), "thrl_nn_reinforce_train")
             torch.cuda.synchronize(self.device)
         self.step += 1
         return grad
