@@ -117,7 +117,8 @@ ISA_KEY = {("rr", "k_mixed_wave"): "k_mixed_wave<float,NR=2,24,2,memo> (2 x Rein
            ("qr", "k_mixed_wave"): "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)",
            ("rr", "k_ptuple_episodes"): "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)",
            ("qr", "k_ptuple_episodes"): "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)",
-           ("rr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>"}
+           ("rr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>",
+           ("rr", "k_nn_returns"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_returns"): "k_nn_reinforce_train<24,false>"}
 
 
 def nn(tag):
@@ -131,7 +132,7 @@ def nn(tag):
         copy_stats(ptag, "r03_nn%s_kernel_stats.csv" % p)
         ks = {}
         total_ns = 0.0
-        for kern in ("k_ptuple_episodes", "k_mixed_wave", "k_nn_reinforce_train"):
+        for kern in ("k_ptuple_episodes", "k_mixed_wave", "k_nn_reinforce_train", "k_nn_returns"):
             c, geom = collect(ptag, kern)
             st = stats(ptag, kern)
             if not c or not st:
