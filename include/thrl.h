@@ -56,7 +56,7 @@ typedef enum {
     THRL_KERNEL_WAVE = 2,       /* one wavefront per game, tables in LDS, f32 / f64 */
     /* The wave kernel has two code variants with IDENTICAL results: the plain one and the greedy-regime one
      * (per-episode composed greedy tables, cyclic segments as register recurrences); THRL_KERNEL_WAVE picks by
-     * epsilon (the greedy one once every agent's epsilon <= 0.035).  These two ids pin the variant for one call
+     * epsilon (the greedy one once every agent's epsilon <= 0.05).  These two ids pin the variant for one call
      * -- measurements and the parity tests that cover each variant in each regime.  _GREEDY fails with
      * THRL_ERR_UNSUPPORTED where no greedy variant exists (noise, sweeps, multi-episode training cycles). */
     THRL_KERNEL_WAVE_PLAIN = 3,

@@ -384,7 +384,7 @@ def test_wave_greedy_regime_cycles_and_fixed_points_vs_oracle(dtype, eps):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_wave_greedy_variant_equals_generic_kernel_at_16384_games(dtype):
-    """The GREEDY variants of the wave kernel (launched once epsilon <= 0.035: all-greedy groups without a table
+    """The GREEDY variants of the wave kernel (launched once epsilon <= 0.05: all-greedy groups without a table
     build, period-2 passes, cyclic segments of period 1-4 as register recurrences) against the generic kernel --
     independent code, one thread per game, tables in HBM -- on 16,384 games over 40 episodes that start at
     epsilon 0.02: tables, counters, states and epsilon bit for bit; and the regime really is the cyclic one."""

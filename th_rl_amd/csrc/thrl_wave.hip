@@ -64,7 +64,7 @@ int launch_wave_lut(const WaveArgs& a, unsigned char* out, hipStream_t s) {
 
 // (THRL_GREEDY_EPS overrides the threshold for measurements; read once per process)
 static double greedy_eps() {
-    static const double v = [] { const char* e = getenv("THRL_GREEDY_EPS"); return e ? atof(e) : 0.035; }();
+    static const double v = [] { const char* e = getenv("THRL_GREEDY_EPS"); return e ? atof(e) : 0.05; }();
     return v;
 }
 
@@ -72,11 +72,11 @@ int launch_wave(const WaveArgs& a, int q_dtype, int grid, int block, size_t lds,
     const bool sweep = a.sw_gamma || a.sw_alpha || a.sw_eps_end || a.sw_eps_step || a.sw_eps || a.sw_noise_prob;
     const int variant = sweep ? 2 : (a.env.noise_prob > 0.0 ? 1 : 0);     // sweep: noise code present, taken per game
     const bool cycle = a.epk > 1 || a.replay_from > 0;                    // (never together with sweeps: thrl_api.hip)
-    // Once both agents explore in fewer than ~3.5 % of their steps the variant that skips the table build of all-greedy
+    // Once both agents explore in fewer than ~5 % of their steps the variant that skips the table build of all-greedy
     // groups of four steps and runs cyclic segments as register recurrences is the faster one: measured on trained
-    // tables (262,144 games), plain vs GREEDY: 3.12 vs 2.95e10 at epsilon 0.068, 3.07 vs 3.04 at 0.042, 2.98 vs 3.14 at
-    // 0.026, 2.89 vs 3.33 at 0.010 -- its per-group tests cost up to 6 % while the agents still explore.  Same results
-    // either way.
+    // tables along a run (262,144 games, round 3, profiles/exp_greedy_threshold.py), plain vs GREEDY: 3.05 vs 2.97e10 at
+    // epsilon 0.069, 3.01 vs 3.01 at 0.054, 2.98 vs 3.06 at 0.042, 2.93 vs 3.15 at 0.026, 2.81 vs 3.44 at 0.0065 -- its
+    // per-group tests cost while the agents still explore.  Same results either way.
     const bool greedy_exists = !cycle && variant == 0;
     if (a.force_variant == 2 && !greedy_exists) return -2;               // (thrl_api.hip turns it into THRL_ERR_UNSUPPORTED)
     const bool greedy = greedy_exists && a.force_variant != 1 &&
