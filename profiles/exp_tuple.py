@@ -10,8 +10,12 @@ THREE = {"agents": [dict(AG, actions=11, states=50, action_range=[0.1, 0.3], min
                     dict(AG, actions=5, states=20, action_range=[0.0, 0.3], min_memory=25, max_state=10)],
          "environment": dict(ENV, nplayers=3, max_steps=25)}
 TWO_GRIDS = {"agents": [dict(AG, actions=15, min_memory=100), dict(AG, actions=21, action_range=[0.15, 0.45])], "environment": dict(ENV)}
+def noisy(cfg, p=0.05):
+    return {"agents": cfg["agents"], "environment": dict(cfg["environment"], noise_prob=p)}
 for name, cfg, G in (("three players (11/21/5 actions, T=25)", THREE, 65536), ("three players", THREE, 1 << 20),
-                     ("two agents, different grids (15/21 actions, T=100)", TWO_GRIDS, 65536)):
+                     ("two agents, different grids (15/21 actions, T=100)", TWO_GRIDS, 65536),
+                     ("three players, noise_prob 0.05", noisy(THREE), 65536),
+                     ("two agents, different grids, noise_prob 0.05", noisy(TWO_GRIDS), 65536)):
     for kern in ("tuple", "generic"):
         if kern == "generic" and G > 65536:
             continue

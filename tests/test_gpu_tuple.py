@@ -60,6 +60,15 @@ A33 = dict(CFG_AGENT, actions=33, states=64, action_range=[0.0, 0.5], min_memory
     ("A33_three_columns_per_lane", _cfg([A33, A3], 30), 33, 4),
     ("greedy_regime", _cfg([dict(A1, epsilon=0.0, eps_end=0.0), dict(A2, epsilon=0.02, eps_end=0.02), dict(A3, epsilon=0.0, eps_end=0.0)], 50), 90, 6),
     ("many_episodes_two_launches", THREE, 19, 40),
+    # env noise (environments.py:28-31): a step with a redrawn intercept leaves the action grid
+    ("three_players_noise05", {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=0.05)}, 137, 7),
+    ("four_agents_noise30", _cfg([A1, A3, A4, A3], 20, noise_prob=0.3), 41, 6),
+    ("T65_two_segments_noise50", _cfg([A1, A3], 65, noise_prob=0.5), 33, 4),
+    ("T130_three_segments_noise10", _cfg([A3, A4, A3], 130, noise_prob=0.1), 21, 3),
+    ("every_step_noisy", _cfg([A1, A2], 40, noise_prob=1.0), 40, 5),
+    ("one_agent_noise20", _cfg([dict(A2, action_range=[0.3, 0.9])], 30, noise_prob=0.2), 50, 5),
+    ("greedy_regime_noise05", _cfg([dict(A1, epsilon=0.0, eps_end=0.0), dict(A2, epsilon=0.02, eps_end=0.02), dict(A3, epsilon=0.0, eps_end=0.0)], 50, noise_prob=0.05), 90, 6),
+    ("many_episodes_two_launches_noise", {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=0.1)}, 19, 40),
 ])
 def test_tuple_kernel_vs_oracle(label, config, G, E, dtype):
     """Philox draws, both table dtypes: tables, visit counters, env state and epsilon bit-identical to the oracle over two
@@ -92,7 +101,7 @@ def _tuple_eligible(path):
     ag, env = c["agents"], c["environment"]
     T = env["max_steps"]
     tuples = int(np.prod([a["actions"] for a in ag]))
-    return (len(ag) <= 4 and env.get("noise_prob", 0.05) == 0 and T <= 256 and tuples <= 4096
+    return (len(ag) <= 4 and T <= 256 and tuples <= 4096
             and all(a.get("min_memory", 100) <= T <= a.get("capacity", 500) and a["actions"] <= 64 for a in ag))
 
 
@@ -101,10 +110,11 @@ def _golden_files():
 
 
 def test_golden_coverage_of_the_tuple_kernel():
-    """Which reference-generated fixtures the kernel can take (the others have env noise or replay buffers that span
-    episodes / overflow: the generic kernel's)."""
+    """Which reference-generated fixtures the kernel can take (the others have replay buffers that span episodes /
+    overflow: the generic kernel's), the noisy ones included."""
     names = [os.path.basename(p) for p in _golden_files() if _tuple_eligible(p)]
     assert "g5_three_players_seed9_e30.npz" in names and any(n.startswith("g4_") for n in names), names
+    assert "g5_hetero_noise_seed5_e20.npz" in names, names
 
 
 @pytest.mark.parametrize("path", [p for p in _golden_files() if _tuple_eligible(p)], ids=os.path.basename)
@@ -116,7 +126,10 @@ def test_tuple_f64_injected_matches_reference_golden(path):
     E, T, N = d["u"].shape
     gb = _batch(config, 1, dtype="float64", kernel="tuple")
     gb.set_tables(d["init_tables"][None, :], [float(d["state0"])])
-    out = gb.run(E, inj=dict(u=d["u"][:, :, :, None], choice=d["choice"][:, :, :, None]))
+    inj = dict(u=d["u"][:, :, :, None], choice=d["choice"][:, :, :, None])
+    if config["environment"].get("noise_prob", 0.05) > 0:
+        inj.update(noise_u=d["noise_u"][:, :, None], noise_a=d["noise_a"][:, :, None])
+    out = gb.run(E, inj=inj)
     assert out["kernel"] == "tuple"
     assert np.array_equal(gb.tables_numpy()[0], d["final_tables"])
     assert np.array_equal(gb.counters_numpy()[0].astype(np.float64), d["final_counters"])
@@ -134,9 +147,12 @@ def test_auto_selects_the_tuple_kernel_and_refusals():
     cfg2 = {"agents": [dict(CFG_AGENT), dict(CFG_AGENT)], "environment": dict(CFG_ENV)}
     assert _batch(cfg2, 64, kernel="auto").init_tables().run(1)["kernel"] == "wave"
     noisy = {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=0.05)}
+    assert _batch(noisy, 8, kernel="auto").init_tables().run(1)["kernel"] == "tuple"
+    # more than 4,096 action tuples: the one-thread-per-game kernel
+    big = _cfg([dict(A2, actions=40), dict(A2, actions=40), dict(A3, actions=3)], 20)
     with pytest.raises(ThrlError, match="tuple kernel cannot run"):
-        _batch(noisy, 8, kernel="tuple").init_tables().run(1)
-    assert _batch(noisy, 8, kernel="auto").init_tables().run(1)["kernel"] == "generic"
+        _batch(big, 8, kernel="tuple").init_tables().run(1)
+    assert _batch(big, 8, kernel="auto").init_tables().run(1)["kernel"] == "generic"
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
@@ -159,8 +175,8 @@ def test_tuple_equals_generic_at_65536_games_three_players(dtype):
     assert torch.equal(half.q, a.q[30000:31000]) and torch.equal(half.counter, a.counter[30000:31000])
 
 
-def _random_tuple_config(rs):
-    """A random configuration the tuple-chain kernel must take: 1-4 agents, individual grids, no noise, buffers that train
+def _random_tuple_config(rs, noise=0.0):
+    """A random configuration the tuple-chain kernel must take: 1-4 agents, individual grids, buffers that train
     once per episode, <= 4,096 action tuples."""
     while True:
         n = int(rs.choice([1, 2, 3, 3, 4]))
@@ -177,7 +193,7 @@ def _random_tuple_config(rs):
                            action_range=[lo, float(np.round(lo + rs.uniform(0.02, 0.6 / n), 2))],
                            max_state=float(rs.choice([10, 10, 12])), min_memory=int(rs.choice([0, 1, max(1, T // 2), T])),
                            capacity=int(rs.choice([T, T + 3, 500]))))
-    return {"agents": agents, "environment": dict(name="NoisyPriceState", noise_prob=0.0, a=10, b=1, nplayers=n, max_steps=T)}
+    return {"agents": agents, "environment": dict(name="NoisyPriceState", noise_prob=noise, a=10, b=1, nplayers=n, max_steps=T)}
 
 
 @pytest.mark.parametrize("case", range(24))
@@ -200,3 +216,38 @@ def test_tuple_kernel_fuzz_vs_oracle(case):
     assert np.array_equal(gb.counters_numpy(), c) and np.array_equal(gb.states_numpy(), s), label
     np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12, atol=1e-13, err_msg=label)
     np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13, err_msg=label)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_tuple_kernel_noise_fuzz_vs_oracle(case):
+    """Random configurations with env noise, kernel forced: bit-identical to the oracle."""
+    rs = np.random.RandomState(9100 + case)
+    config = _random_tuple_config(rs, noise=float(rs.choice([0.01, 0.05, 0.2, 0.5, 1.0])))
+    dtype = "float64" if case % 3 == 1 else "float32"
+    G, E = int(rs.randint(1, 70)), int(rs.choice([1, 3, 9, 35]))
+    if config["environment"]["max_steps"] * G * E > 400000:
+        E = 3
+    seed, off = int(rs.randint(0, 10 ** 6)), int(rs.randint(0, 1 << 33))
+    gb = _batch(config, G, dtype=dtype, kernel="tuple", seed=seed, game_offset=off).init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    out = gb.run(E)
+    label = "%s %s G=%d E=%d -> %s" % (json.dumps(config)[:300], dtype, G, E, out["kernel"])
+    assert out["kernel"] == "tuple", label
+    q, c, s, eps, oo = _oracle(config, G, dtype, q0, s0, E, seed=seed, game_offset=off)
+    assert np.array_equal(gb.tables_numpy(), q), label
+    assert np.array_equal(gb.counters_numpy(), c) and np.array_equal(gb.states_numpy(), s), label
+    np.testing.assert_allclose(out["reward_log"], oo["reward_log"], rtol=1e-12, atol=1e-13, err_msg=label)
+    np.testing.assert_allclose(out["action_log"], oo["action_log"], rtol=1e-12, atol=1e-13, err_msg=label)
+
+
+def test_tuple_equals_generic_at_65536_games_three_players_with_noise():
+    """The reference's default noise_prob (0.05) at BASELINE configs[1] size: tuple kernel == generic kernel on device."""
+    import torch
+    noisy = {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=0.05)}
+    G, E = 65536, 8
+    a = _batch(noisy, G, kernel="tuple", seed=5).init_tables()
+    b = _batch(noisy, G, kernel="generic", seed=5).init_tables()
+    ra, rb = a.run(E), b.run(E)
+    assert ra["kernel"] == "tuple" and rb["kernel"] == "generic"
+    assert torch.equal(a.q, b.q) and torch.equal(a.counter, b.counter) and torch.equal(a.state, b.state)
+    np.testing.assert_allclose(ra["reward_log"], rb["reward_log"], rtol=1e-12)

@@ -448,8 +448,8 @@ def test_oracle_golden_under_sanitizers():
 
 def test_kernel_selection_covers_individual_grids_on_the_host(lib):
     """thrl_select_kernel / thrl_workspace_bytes (host logic, no GPU): two agents on one grid -> the wave kernel; 1-4 agents with
-    individual grids in a noise-free game that trains once per episode -> the tuple-chain kernel; noise, buffers that span
-    episodes, five agents or too many action tuples -> the generic kernel."""
+    individual grids in a game (with or without env noise) that trains once per episode -> the tuple-chain kernel; buffers that
+    span episodes, five agents or too many action tuples -> the generic kernel."""
     from th_rl_amd import _lib
     def sel(agents, **env):
         conf = {"agents": agents, "environment": dict(CFG_ENV, nplayers=len(agents), **env)}
@@ -463,7 +463,7 @@ def test_kernel_selection_covers_individual_grids_on_the_host(lib):
     assert k == "tuple" and ws == 160 * 1024
     assert sel([a11, dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                 # two agents, different grids
     assert sel([dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                     # one agent
-    assert sel([a11, dict(a21, min_memory=25), a5], max_steps=25, noise_prob=0.05)[0] == "generic"
+    assert sel([a11, dict(a21, min_memory=25), a5], max_steps=25, noise_prob=0.05)[0] == "tuple"
     assert sel([a11, dict(a21, min_memory=25), a5], max_steps=10)[0] == "generic"           # buffers fill every 3rd episode
     assert sel([a5] * 5, max_steps=25)[0] == "generic"                                      # five agents
     assert sel([a21, a21, dict(a21, action_range=[0.0, 0.1])], max_steps=100)[0] == "generic"   # 9,261 action tuples

@@ -271,7 +271,6 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
 #define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
     const int N = c->n_agents, T = c->max_steps;
     if (N < 1 || N > kTupMaxN) NO("more than 4 agents");
-    if (c->noise_prob > 0.0) NO("environment noise (the state must be a function of the action tuple)");
     if (T > 256) NO("more than 256 steps per episode");
     long tuples = 1;
     for (int i = 0; i < N; i++) {
@@ -285,7 +284,8 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     }
     TupleArgs& a = p.a;
     a.N = N; a.T = T; a.tuples = (int)tuples;
-    // row windows: both encodes of the price of every tuple
+    // row windows: both encodes of the price of every tuple; with noise the intercept ranges over [0.7a, a]
+    // (environments.py:29-31) and both encodes are monotonic in the price, so the two ends cover the range
     int lo[kTupMaxN], hi[kTupMaxN];
     for (int i = 0; i < N; i++) { lo[i] = 1 << 30; hi[i] = -1; }
     const double ratio = c->env_a / c->env_b;
@@ -293,13 +293,16 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     for (long t = 0; t < tuples; t++) {
         double Q = 0.0;
         for (int i = 0; i < N; i++) Q = Q + ratio * h_scale(digit[i], c, i);
-        double price = c->env_a - c->env_b * Q;
-        if (!(price > 0.0)) price = 0.0;
-        for (int i = 0; i < N; i++) {
-            const int r64 = h_encode64(price, c, i), r32 = h_encode32(price, c, i);
-            if (r64 < 0 || r64 > c->n_states[i] || r32 < 0 || r32 > c->n_states[i]) NO("price outside a table on the action grid");
-            lo[i] = r64 < lo[i] ? r64 : lo[i]; lo[i] = r32 < lo[i] ? r32 : lo[i];
-            hi[i] = r64 > hi[i] ? r64 : hi[i]; hi[i] = r32 > hi[i] ? r32 : hi[i];
+        const double intercepts[2] = {c->env_a, c->env_a * 0.7};
+        for (int v = 0; v < (c->noise_prob > 0.0 ? 2 : 1); v++) {
+            double price = intercepts[v] - c->env_b * Q;
+            if (!(price > 0.0)) price = 0.0;
+            for (int i = 0; i < N; i++) {
+                const int r64 = h_encode64(price, c, i), r32 = h_encode32(price, c, i);
+                if (r64 < 0 || r64 > c->n_states[i] || r32 < 0 || r32 > c->n_states[i]) NO("price outside a table on the action grid");
+                lo[i] = r64 < lo[i] ? r64 : lo[i]; lo[i] = r32 < lo[i] ? r32 : lo[i];
+                hi[i] = r64 > hi[i] ? r64 : hi[i]; hi[i] = r32 > hi[i] ? r32 : hi[i];
+            }
         }
         for (int i = N - 1; i >= 0; i--) { if (++digit[i] < c->n_actions[i]) break; digit[i] = 0; }     // last agent = fastest digit
     }
@@ -322,7 +325,8 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     a.aq_off = (int)align_up((size_t)tuples * N * 2, 16);
     a.lut_lds_bytes = a.aq_off + N * 64 * 8 * 2;
     a.price_off = a.lut_lds_bytes;
-    p.lut_image_bytes = (size_t)a.price_off + 8 * (size_t)tuples;
+    a.qsum_off = a.price_off + 8 * (int)tuples;
+    p.lut_image_bytes = (size_t)a.qsum_off + 8 * (size_t)tuples;
     if (p.lut_image_bytes > kTupleWsBytes - 64) NO("LUT image too large");
     const DevInfo dv = dev_info();
     int cap_waves = dv.waves_per_cu < 16 ? dv.waves_per_cu : 16;         // the kernel is compiled for 4 waves per SIMD
@@ -415,8 +419,10 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
 size_t thrl_workspace_bytes(const thrl_cfg* c) {
     if (validate(c) != THRL_OK) return 0;
     const WavePlan p = plan_wave(c, nullptr, false);
-    if (!p.ok) return plan_tuple(c, nullptr).ok ? kTupleWsBytes : kLutRegion;      // (the generic kernel keeps nothing there)
-    return wave_workspace(c, p).bytes;
+    const size_t tuple_ws = plan_tuple(c, nullptr).ok ? kTupleWsBytes : kLutRegion;  // (the generic kernel keeps nothing there)
+    if (!p.ok) return tuple_ws;
+    const size_t wave_ws = wave_workspace(c, p).bytes;                               // (either kernel can be asked for by id)
+    return wave_ws > tuple_ws ? wave_ws : tuple_ws;
 }
 int thrl_select_kernel(const thrl_cfg* c, int injected) {
     if (validate(c) != THRL_OK) return THRL_ERR_BAD_CONFIG;
@@ -611,6 +617,8 @@ static int run_wave(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, con
 
 static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, TuplePlan& p, hipStream_t s) {
     if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
+    if (b->inj_u && c->noise_prob > 0.0 && (!b->inj_noise_u || !b->inj_noise_a))
+        return fail(THRL_ERR_NULL, "injected draws with noise_prob > 0 need inj_noise_u / inj_noise_a");
     if (!b->workspace || b->workspace_bytes < kTupleWsBytes)
         return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes, kTupleWsBytes);
     if ((b->reward_log == nullptr) != (b->action_log == nullptr))
@@ -652,6 +660,10 @@ static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, Tu
             const size_t per_ep = (size_t)c->max_steps * a.N * (size_t)c->n_games;
             a.inj_u = b->inj_u + (size_t)done * per_ep;
             a.inj_choice = b->inj_choice + (size_t)done * per_ep;
+            if (c->noise_prob > 0.0) {
+                a.inj_noise_u = b->inj_noise_u + (size_t)done * c->max_steps * (size_t)c->n_games;
+                a.inj_noise_a = b->inj_noise_a + (size_t)done * c->max_steps * (size_t)c->n_games;
+            }
         }
         for (int ep = 0; ep < n; ep++)
             for (int i = 0; i < a.N; i++) {

@@ -88,6 +88,7 @@ struct TupleArgs {
     int32_t waves_per_block, total_waves;
     int32_t lut_lds_bytes;          // LDS-staged part of the LUT image: rows16 [tuples][N], then aq / sct [N][64] doubles
     int32_t aq_off, price_off;      // byte offsets in the image: aq (inside the staged part), price [tuples] (HBM only)
+    int32_t qsum_off;               // total quantity per tuple [tuples] doubles (HBM only; games with env noise)
     int32_t game_lds_bytes;         // per wave: tables | greedy-action bytes | G table | visit histogram
     int32_t tab_off[kTupMaxN];      // element offset of agent i's window (+ 2 spill rows) in the per-game table region
     int32_t am_off, am_off_i[kTupMaxN];      // byte offsets
@@ -102,6 +103,7 @@ struct TupleArgs {
     double* sum_reward; double* sum_action;      // device [n_episodes][N] sums over games (zeroed by the host) or null
     int32_t* next_game;             // device: work counter of the launch, zeroed by the host
     const double* inj_u; const int8_t* inj_choice;   // parity mode: [n_episodes][T][N][G], or null (Philox)
+    const double* inj_noise_u; const double* inj_noise_a;      // parity mode with noise: [n_episodes][T][G]
     uint64_t seed, game_offset, first_episode;
     double eps[kTupMaxEpisodes][kTupMaxN];
 };
@@ -109,6 +111,8 @@ int launch_tuple_lut(const TupleArgs& a, unsigned char* out, hipStream_t s);
 int launch_tuple(const TupleArgs& a, int q_dtype, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_tuple_f32(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_tuple_f64(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f32_noise(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f64_noise(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 
 // ---- two-agent games with discrete neural-policy agents on the tuple-chain design (thrl_ptuple.hip)
 struct PTupleArgs {

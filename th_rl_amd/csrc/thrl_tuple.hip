@@ -4,7 +4,8 @@
 
 namespace thrl {
 
-// LUT image: rows16 [tuples][N] (play row | train row << 8, window-local), aq [N][64], sct [N][64], price [tuples]
+// LUT image: rows16 [tuples][N] (play row | train row << 8, window-local), aq [N][64], sct [N][64], price [tuples],
+// qsum [tuples] (total quantity of the tuple: the price under a redrawn intercept is max(0, a' - b * qsum))
 __global__ void __launch_bounds__(256) k_tuple_lut(const TupleArgs a, unsigned char* out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = a.N;
@@ -16,6 +17,9 @@ __global__ void __launch_bounds__(256) k_tuple_lut(const TupleArgs a, unsigned c
         for (int i = 0; i < N; i++) scaled[i] = scale_action(digit[i], a.ag[i]);
         const double price = env_step<kTupMaxN>(a.env, N, scaled, a.env.a, rew);          // environments.py:25-39
         reinterpret_cast<double*>(out + a.price_off)[idx] = price;
+        double Q = 0.0;
+        for (int i = 0; i < N; i++) Q = __dadd_rn(Q, __dmul_rn(a.env.ratio, scaled[i]));          // as env_step sums it
+        reinterpret_cast<double*>(out + a.qsum_off)[idx] = Q;
         for (int i = 0; i < N; i++) {
             const int W = a.win_rows[i];
             const int rp = min(max(encode32(price, a.ag[i]) - a.row_lo[i], 0), W - 1);     // play row (trainer.py:53)
@@ -38,6 +42,7 @@ int launch_tuple_lut(const TupleArgs& a, unsigned char* out, hipStream_t s) {
 }
 
 int launch_tuple(const TupleArgs& a, int q_dtype, int grid, int block, size_t lds, hipStream_t s) {
+    if (a.env.noise_prob > 0.0) return q_dtype == 1 ? launch_tuple_f64_noise(a, grid, block, lds, s) : launch_tuple_f32_noise(a, grid, block, lds, s);
     return q_dtype == 1 ? launch_tuple_f64(a, grid, block, lds, s) : launch_tuple_f32(a, grid, block, lds, s);
 }
 

@@ -5,7 +5,7 @@
 // agents, per-agent state / action grids, per-agent max_state (the reference allows any nplayers and any QTable
 // per agent: th_rl/trainer.py:21-23, agents.py:13-28).  Same semantics as thrl_generic.hip and bit-identical results
 // to it and to the oracle: trainer.train_one's loop (trainer.py:46-70) with QTable.sample_action (agents.py:80-89),
-// scale (:51-57), NoisyPriceState.step (environments.py:25-39, noise_prob == 0), ReplayBuffer append / replay / empty
+// scale (:51-57), NoisyPriceState.step (environments.py:25-39), ReplayBuffer append / replay / empty
 // and QTable.train_net (agents.py:59-78) for `n_episodes` episodes per launch.
 //
 // Idea: without noise the state after a step is a function of that step's ACTION TUPLE, so a game's state is a
@@ -25,6 +25,11 @@
 //     the TD value; step operands reach the 16-lane rows by ds_bpermute per 16 steps and row_newbcast DPP per step.
 //     Strictly one transition at a time per agent, in order: no hazard analysis needed.
 //   * visit counters: u16 histogram in LDS beside the tables, applied to the int32 counters once per launch.
+//   * env noise (template NOISE, noise_prob > 0): a step whose intercept was redrawn (environments.py:29-31) leaves the
+//     action grid.  The state after it is carried as explicit rows (both encodes of its price, computed once on the
+//     chain from qsum[tau] = the tuple's total quantity); the step played in it reads the agents' greedy actions from
+//     the per-row bytes instead of G[tau]; every other step is the plain chain step.  The row windows cover the
+//     prices of every tuple for every intercept in [0.7a, a].
 #pragma once
 #include <type_traits>
 #include "thrl_kernels.h"
@@ -168,7 +173,7 @@ __device__ __forceinline__ void replay_step(uint32_t xw, const Ops<QT>& xo, unsi
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename QT, int N, int NSEG>
+template <typename QT, int N, int NSEG, bool NOISE>
 __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -184,6 +189,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     const double* lut_aq = reinterpret_cast<const double*>(smem + a.aq_off);                        // [N][64]
     const double* lut_sct = lut_aq + N * 64;                                                         // [N][64]
     const double* price_lut = reinterpret_cast<const double*>(a.lut + a.price_off);                 // [tuples], HBM / L2
+    const double* qsum_lut = reinterpret_cast<const double*>(a.lut + a.qsum_off);                   // [tuples], HBM / L2 (NOISE)
     unsigned char* game = smem + a.lut_lds_bytes + (size_t)wib * a.game_lds_bytes;
     QT* const tabs = reinterpret_cast<QT*>(game);
     unsigned char* const am = game + a.am_off;
@@ -249,6 +255,17 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         int tau = tuples;                    // current state: action tuple of the last step; `tuples` = the launch's initial state
+        // NOISE: a step whose intercept was redrawn (environments.py:29-31) leaves the action grid -- the state after it is
+        // "off": its rows are carried explicitly (byte i = agent i's window-local play / train row) instead of a tuple.
+        // The launch's initial state is handled the same way.
+        bool off = NOISE;
+        uint32_t offp = 0u, offt = 0u;
+        double p_off = price0;
+        if (NOISE) {
+            tau = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) { offp |= (uint32_t)init_play[i] << (8 * i); offt |= (uint32_t)init_train[i] << (8 * i); }
+        }
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
 
@@ -318,22 +335,74 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 }
                 Mw[seg] = mw; Cw[seg] = cw;
             }
-
-            // ---- (d) play: the serial chain, on the scalar unit.  seq[seg] lane t = state (tuple) step t was played in
-            uint32_t seq[NSEG];
+            // NOISE: the env's draw of every step (environments.py:28-31): nzm bit t = intercept redrawn, NA = its value
+            uint64_t nzm[NSEG];
+            double NA[NSEG];
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
-                seq[seg] = 0u;
+                nzm[seg] = 0ull; NA[seg] = a.env.a;
+                if (NOISE) {
+                    const int tt = min(seg * 64 + lane, T - 1);
+                    double nu, na;
+                    if (a.inj_u) {
+                        const size_t k = ((size_t)e * T + tt) * (size_t)a.G + (size_t)g;
+                        nu = a.inj_noise_u[k]; na = a.inj_noise_a[k];
+                    } else {
+                        const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)tt, kStreamNoise);
+                        nu = u01_32(xn.x);
+                        na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
+                    }
+                    nzm[seg] = __ballot(seg * 64 + lane < T && nu < a.env.noise_prob);
+                    NA[seg] = na;
+                }
+            }
+
+            // ---- (d) play: the serial chain, on the scalar unit.  seq[seg] lane t = state (tuple) step t was played in
+            // (NOISE: the packed train rows where that state is off the grid; acts[seg] lane t = the actions of step t)
+            uint32_t seq[NSEG], acts[NSEG];
+            const bool off0 = off;
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                seq[seg] = 0u; acts[seg] = 0u;
                 const int n = min(64, T - seg * 64);
                 for (int tl = 0; tl < n; tl++) {
-                    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
+                    uint32_t w;
+                    if (NOISE && off) {
+                        uint32_t wv = 0u;
+#pragma unroll
+                        for (int i = 0; i < N; i++) wv |= (uint32_t)am[a.am_off_i[i] + (int)((offp >> (8 * i)) & 0xFFu)] << (8 * i);
+                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
+                    } else {
+                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
+                    }
                     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)Mw[seg], tl), c = (uint32_t)__builtin_amdgcn_readlane((int)Cw[seg], tl);
                     const uint32_t ap = (c & m) | (w & ~m);
-                    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(seq[seg]) : "s"(tau), "s"(tl));
+                    const uint32_t rec = (NOISE && off) ? offt : (uint32_t)tau;
+                    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(seq[seg]) : "s"(rec), "s"(tl));
+                    if (NOISE) asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(acts[seg]) : "s"(ap), "s"(tl));
                     int nt = 0;
 #pragma unroll
                     for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)((ap >> (8 * i)) & 0xFFu);
                     tau = nt;
+                    if (NOISE) {
+                        off = (nzm[seg] >> tl) & 1ull;
+                        if (off) {           // environments.py:29-33 with the redrawn intercept; rows by both encodes
+                            const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(NA[seg]), tl),
+                                                               __builtin_amdgcn_readlane(__double2loint(NA[seg]), tl));
+                            double pr = __dsub_rn(na, __dmul_rn(a.env.b, qsum_lut[tau]));
+                            if (!(pr > 0.0)) pr = 0.0;
+                            uint32_t op = 0u, ot = 0u;
+#pragma unroll
+                            for (int i = 0; i < N; i++) {
+                                const int W = a.win_rows[i];
+                                op |= (uint32_t)min(max(encode32(pr, a.ag[i]) - a.row_lo[i], 0), W - 1) << (8 * i);
+                                ot |= (uint32_t)min(max(encode64(pr, a.ag[i]) - a.row_lo[i], 0), W - 1) << (8 * i);
+                            }
+                            offp = (uint32_t)__builtin_amdgcn_readfirstlane((int)op);
+                            offt = (uint32_t)__builtin_amdgcn_readfirstlane((int)ot);
+                            p_off = pr;
+                        }
+                    }
                 }
             }
             const int tau_end = tau;
@@ -348,20 +417,49 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             for (int seg = 0; seg < NSEG; seg++) {
                 const int tt = seg * 64 + lane;
                 const bool valid = tt < T;
-                const int tq = valid ? (int)seq[seg] : tau_end;
-                int nxt = __shfl_down((int)seq[seg], 1, 64);
-                if (seg + 1 < NSEG) { if (lane == 63) nxt = __builtin_amdgcn_readlane((int)seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
-                if (tt + 1 >= T) nxt = tau_end;
-                const uint32_t w = gt[tq];
-                const uint32_t ap = (Cw[seg] & Mw[seg]) | (w & ~Mw[seg]);
-                const double price = price_lut[nxt];
+                const uint32_t end_word = (NOISE && off) ? offt : (uint32_t)tau_end;
+                uint32_t tq = valid ? seq[seg] : end_word;
+                uint32_t nxt = (uint32_t)__shfl_down((int)seq[seg], 1, 64);
+                if (seg + 1 < NSEG) { if (lane == 63) nxt = (uint32_t)__builtin_amdgcn_readlane((int)seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
+                if (tt + 1 >= T) nxt = end_word;
+                // NOISE: is my state / the state after my step off the grid (its word = packed train rows, not a tuple)?
+                bool s_off = false, n_off = false;
+                if (NOISE) {
+                    n_off = valid && ((nzm[seg] >> lane) & 1ull);
+                    s_off = lane > 0 ? (bool)((nzm[seg] >> (lane - 1)) & 1ull) : (seg > 0 ? (bool)((nzm[seg > 0 ? seg - 1 : 0] >> 63) & 1ull) : off0);
+                    if (!valid) { s_off = false; tq = 0u; n_off = false; nxt = 0u; }
+                }
+                uint32_t ap;
+                double price;
+                if (NOISE) {
+                    ap = acts[seg];
+                    int nt = 0;
+#pragma unroll
+                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)((ap >> (8 * i)) & 0xFFu);
+                    if (!valid) nt = 0;
+                    price = price_lut[nt];
+                    if (n_off) {
+                        price = __dsub_rn(NA[seg], __dmul_rn(a.env.b, qsum_lut[nt]));
+                        if (!(price > 0.0)) price = 0.0;
+                    }
+                } else {
+                    const uint32_t w = gt[tq];
+                    ap = (Cw[seg] & Mw[seg]) | (w & ~Mw[seg]);
+                    price = price_lut[nxt];
+                }
 #pragma unroll
                 for (int i = 0; i < N; i++) {
                     const AgentParams& p = a.ag[i];
                     const int A = p.n_actions;
                     const uint32_t act = valid ? ((ap >> (8 * i)) & 0xFFu) : 0u;
-                    const uint32_t srow = tq == tuples ? (uint32_t)init_train[i] : (uint32_t)(rows16[tq * N + i] >> 8);
-                    const uint32_t ns = (uint32_t)(rows16[nxt * N + i] >> 8);
+                    uint32_t srow, ns;
+                    if (NOISE) {
+                        srow = s_off ? ((tq >> (8 * i)) & 0xFFu) : (uint32_t)(rows16[(s_off ? 0u : tq) * N + i] >> 8);
+                        ns = n_off ? ((nxt >> (8 * i)) & 0xFFu) : (uint32_t)(rows16[(n_off ? 0u : nxt) * N + i] >> 8);
+                    } else {
+                        srow = tq == (uint32_t)tuples ? (uint32_t)init_train[i] : (uint32_t)(rows16[tq * N + i] >> 8);
+                        ns = (uint32_t)(rows16[nxt * N + i] >> 8);
+                    }
                     const uint32_t cell = valid ? srow * (uint32_t)A + act : 0u;
                     const double aq = lut_aq[i * 64 + act];
                     const double re = __dmul_rn(price, aq);                       // environments.py:33
@@ -446,7 +544,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 }
             }
         }
-        if (lane == 0 && a.n_episodes > 0) a.state[g] = price_lut[tau];
+        if (lane == 0 && a.n_episodes > 0) a.state[g] = (NOISE && off) ? p_off : price_lut[tau];
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -463,12 +561,12 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     }
 }
 
-template <typename QT, int N>
+template <typename QT, int N, bool NOISE>
 static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
 #define THRL_TUP_LAUNCH(NS)                                                                                          \
     {                                                                                                                \
-        auto kern = k_tuple_episodes<QT, N, NS>;                                                                     \
+        auto kern = k_tuple_episodes<QT, N, NS, NOISE>;                                                              \
         if (lds > 64 * 1024) {                                                                                       \
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
@@ -483,13 +581,13 @@ static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, h
 #undef THRL_TUP_LAUNCH
 }
 
-template <typename QT>
+template <typename QT, bool NOISE>
 static int launch_tuple_t(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     switch (a.N) {
-        case 1: return launch_tuple_n<QT, 1>(a, grid, block, lds, s);
-        case 2: return launch_tuple_n<QT, 2>(a, grid, block, lds, s);
-        case 3: return launch_tuple_n<QT, 3>(a, grid, block, lds, s);
-        case 4: return launch_tuple_n<QT, 4>(a, grid, block, lds, s);
+        case 1: return launch_tuple_n<QT, 1, NOISE>(a, grid, block, lds, s);
+        case 2: return launch_tuple_n<QT, 2, NOISE>(a, grid, block, lds, s);
+        case 3: return launch_tuple_n<QT, 3, NOISE>(a, grid, block, lds, s);
+        case 4: return launch_tuple_n<QT, 4, NOISE>(a, grid, block, lds, s);
     }
     return -1;
 }
