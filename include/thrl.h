@@ -64,7 +64,8 @@ typedef enum {
     /* one wavefront per game, tables in LDS, for 1-4 QTable agents with INDIVIDUAL state / action grids (any
      * nplayers and any QTable per agent: trainer.py:21-23): games (with or without env noise) whose replay buffers
      * train once per episode; the state is carried as the action tuple of the last step, or as explicit table rows
-     * after a step with a redrawn intercept.  AUTO picks it where the two-agent wave kernel does not apply. */
+     * after a step with a redrawn intercept; per-game sweeps (thrl_buffers.sweep_*) are taken, an epsilon-schedule
+     * sweep needs sweep_eps.  AUTO picks it where the two-agent wave kernel does not apply. */
     THRL_KERNEL_TUPLE = 5
 } thrl_kernel;
 

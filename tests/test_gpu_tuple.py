@@ -251,3 +251,46 @@ def test_tuple_equals_generic_at_65536_games_three_players_with_noise():
     assert ra["kernel"] == "tuple" and rb["kernel"] == "generic"
     assert torch.equal(a.q, b.q) and torch.equal(a.counter, b.counter) and torch.equal(a.state, b.state)
     np.testing.assert_allclose(ra["reward_log"], rb["reward_log"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("noise", [0.0, 0.1])
+def test_tuple_kernel_sweeps_vs_oracle(dtype, noise):
+    """Per-game sweeps (gamma, alpha, epsilon schedule, noise_prob: thrl_buffers.sweep_*) on the tuple-chain kernel: three
+    players, 40 episodes = two launches (a game's epsilon survives in sweep_eps), then 3 more; bit for bit against the oracle
+    given the same arrays, and against the generic kernel."""
+    rs = np.random.RandomState(11)
+    config = {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=noise)}
+    G, E, N = 29, 40, 3
+    sweep = dict(gamma=rs.choice([0.35, 0.9, 0.95], (N, G)), alpha=rs.choice([0.05, 0.1, 0.5], (N, G)),
+                 eps=rs.uniform(0.0, 0.9, (N, G)), eps_end=rs.choice([0.0, 0.01], (N, G)), eps_step=rs.choice([0.9, 0.999], (N, G)))
+    if noise > 0:
+        sweep["noise_prob"] = rs.choice([0.0, 0.05, 0.5, 1.0], G)
+    gb = _batch(config, G, dtype=dtype, kernel="auto", seed=31)
+    gb.set_sweep(sweep); gb.init_tables()
+    q0, s0 = gb.tables_numpy(), gb.states_numpy()
+    o1 = gb.run(E); o2 = gb.run(3)
+    assert o1["kernel"] == "tuple" and o2["kernel"] == "tuple"
+    cfg, eps0 = O.cfg_from_config(config, n_games=G, q_dtype=1 if dtype == "float64" else 0)
+    q, st, cn, mem = q0.copy(), s0.copy(), np.zeros(q0.shape, np.int32), O.Memory(cfg)
+    osw = {k: np.array(v, np.float64) for k, v in sweep.items()}      # copies: the oracle updates eps in place
+    eps_start = eps0.copy()
+    oo1 = O.episodes(cfg, q, cn, st, eps0, mem, E, seed=31, sweep=osw)
+    oo2 = O.episodes(cfg, q, cn, st, eps0, mem, 3, seed=31, first_episode=E, sweep=osw)
+    assert np.array_equal(gb.tables_numpy(), q) and np.array_equal(gb.counters_numpy(), cn)
+    assert np.array_equal(gb.states_numpy(), st)
+    assert np.array_equal(gb.sweep["eps"].cpu().numpy(), osw["eps"])
+    np.testing.assert_allclose(o1["reward_log"], oo1["reward_log"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(o2["action_log"], oo2["action_log"], rtol=1e-12, atol=1e-13)
+    gen = _batch(config, G, dtype=dtype, kernel="generic", seed=31)
+    gen.set_sweep(sweep); gen.set_tables(q0, s0)
+    assert gen.run(E)["kernel"] == "generic"
+    gen.run(3)
+    assert np.array_equal(gen.tables_numpy(), q) and np.array_equal(gen.sweep["eps"].cpu().numpy(), osw["eps"])
+    # sweeps of gamma / alpha only (no per-game epsilon array): epsilon follows the host's schedule
+    part = _batch(config, G, dtype=dtype, kernel="tuple", seed=31)
+    part.set_sweep(dict(gamma=sweep["gamma"], alpha=sweep["alpha"])); part.set_tables(q0, s0)
+    assert part.run(E)["kernel"] == "tuple"
+    q2, st2, cn2 = q0.copy(), s0.copy(), np.zeros(q0.shape, np.int32)
+    O.episodes(cfg, q2, cn2, st2, eps_start, O.Memory(cfg), E, seed=31, sweep=dict(gamma=osw["gamma"], alpha=osw["alpha"]))
+    assert np.array_equal(part.tables_numpy(), q2) and np.array_equal(part.counters_numpy(), cn2)

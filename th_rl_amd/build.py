@@ -23,7 +23,7 @@ OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "obj")
 SOURCES = ["thrl_api.hip", "thrl_generic.hip", "thrl_ops.hip", "thrl_wave.hip", "thrl_wave_f32.hip", "thrl_wave_f32c.hip",
            "thrl_wave_f32g.hip", "thrl_wave_f32n.hip", "thrl_wave_f32nc.hip", "thrl_wave_f32s.hip", "thrl_wave_f64.hip", "thrl_wave_f64c.hip", "thrl_wave_f64g.hip",
            "thrl_wave_f64n.hip", "thrl_wave_f64nc.hip", "thrl_wave_f64s.hip", "thrl_nn.hip", "thrl_mixed.hip", "thrl_cac.hip",
-           "thrl_tuple.hip", "thrl_tuple_f32.hip", "thrl_tuple_f64.hip", "thrl_tuple_f32_noise.hip", "thrl_tuple_f64_noise.hip",
+           "thrl_tuple.hip", "thrl_tuple_f32.hip", "thrl_tuple_f64.hip", "thrl_tuple_f32_noise.hip", "thrl_tuple_f64_noise.hip", "thrl_tuple_f32_sweep.hip", "thrl_tuple_f64_sweep.hip",
            "thrl_ptuple.hip"]
 HEADERS = ["thrl_device.h", "thrl_kernels.h", "thrl_wave_lut.h", "thrl_wave_kernel.h", "thrl_tuple_kernel.h", "thrl_policy.h", "thrl_cac.h",
            os.path.join("..", "..", "include", "thrl.h")]

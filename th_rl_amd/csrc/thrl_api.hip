@@ -630,6 +630,8 @@ static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, Tu
     fill_agents(c, ag, &a.env);
     for (int i = 0; i < a.N; i++) a.ag[i] = ag[i];
     a.q = b->q; a.counter = b->counter; a.state = b->state;
+    a.sw_gamma = b->sweep_gamma; a.sw_alpha = b->sweep_alpha; a.sw_eps_end = b->sweep_eps_end;
+    a.sw_eps_step = b->sweep_eps_step; a.sw_eps = b->sweep_eps; a.sw_noise_prob = b->sweep_noise_prob;
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut = lut;
     a.next_game = (int32_t*)((char*)b->workspace + kTupleWsBytes - 64);
@@ -702,7 +704,11 @@ int thrl_qtable_episodes(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run
         // (AUTO prefers the two-agent wave kernel where it applies: decided below; the tuple kernel takes what that one cannot)
         TuplePlan tp = plan_tuple(c, run);
         if (tp.ok && per_game_logs) { tp.ok = false; snprintf(tp.why, sizeof(tp.why), "per-game logs requested"); }
-        if (tp.ok && any_sweep) { tp.ok = false; snprintf(tp.why, sizeof(tp.why), "per-game sweeps"); }
+        if (tp.ok && (b->sweep_eps_end || b->sweep_eps_step) && !b->sweep_eps) {
+            // a game's epsilon must survive from launch to launch: it lives in sweep_eps
+            tp.ok = false; snprintf(tp.why, sizeof(tp.why), "epsilon-schedule sweep without a per-game epsilon array (sweep_eps)");
+        }
+        tp.a.sweep = any_sweep ? 1 : 0;
         if (k == THRL_KERNEL_TUPLE) {
             if (!tp.ok) return fail(THRL_ERR_UNSUPPORTED, "tuple kernel cannot run this config: %s", tp.why);
             return run_tuple(c, b, run, tp, (hipStream_t)stream);

@@ -104,6 +104,10 @@ struct TupleArgs {
     int32_t* next_game;             // device: work counter of the launch, zeroed by the host
     const double* inj_u; const int8_t* inj_choice;   // parity mode: [n_episodes][T][N][G], or null (Philox)
     const double* inj_noise_u; const double* inj_noise_a;      // parity mode with noise: [n_episodes][T][G]
+    // per-game sweeps (null = the scalar parameters), [N][G] except noise_prob [G]; `sweep` = any of them given
+    const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
+    double* sw_eps; const double* sw_noise_prob;
+    int32_t sweep;
     uint64_t seed, game_offset, first_episode;
     double eps[kTupMaxEpisodes][kTupMaxN];
 };
@@ -113,6 +117,8 @@ int launch_tuple_f32(const TupleArgs& a, int grid, int block, size_t lds_bytes, 
 int launch_tuple_f64(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_tuple_f32_noise(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 int launch_tuple_f64_noise(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f32_sweep(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
+int launch_tuple_f64_sweep(const TupleArgs& a, int grid, int block, size_t lds_bytes, hipStream_t s);
 
 // ---- two-agent games with discrete neural-policy agents on the tuple-chain design (thrl_ptuple.hip)
 struct PTupleArgs {

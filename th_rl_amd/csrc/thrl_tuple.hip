@@ -42,6 +42,7 @@ int launch_tuple_lut(const TupleArgs& a, unsigned char* out, hipStream_t s) {
 }
 
 int launch_tuple(const TupleArgs& a, int q_dtype, int grid, int block, size_t lds, hipStream_t s) {
+    if (a.sweep) return q_dtype == 1 ? launch_tuple_f64_sweep(a, grid, block, lds, s) : launch_tuple_f32_sweep(a, grid, block, lds, s);
     if (a.env.noise_prob > 0.0) return q_dtype == 1 ? launch_tuple_f64_noise(a, grid, block, lds, s) : launch_tuple_f32_noise(a, grid, block, lds, s);
     return q_dtype == 1 ? launch_tuple_f64(a, grid, block, lds, s) : launch_tuple_f32(a, grid, block, lds, s);
 }

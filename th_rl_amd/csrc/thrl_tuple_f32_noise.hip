@@ -1,10 +1,10 @@
-// thrl_tuple_f32_noise.hip -- instantiates k_tuple_episodes<float, N, NSEG, true>: games with env noise (thrl_tuple_kernel.h)
+// thrl_tuple_f32_noise.hip -- instantiates k_tuple_episodes<float, N, NSEG, true, false>: games with env noise (thrl_tuple_kernel.h)
 #include "thrl_tuple_kernel.h"
 
 namespace thrl {
 
 int launch_tuple_f32_noise(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
-    return tup::launch_tuple_t<float, true>(a, grid, block, lds, s);
+    return tup::launch_tuple_t<float, true, false>(a, grid, block, lds, s);
 }
 
 }  // namespace thrl

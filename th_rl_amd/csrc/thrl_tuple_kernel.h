@@ -30,6 +30,7 @@
 //     chain from qsum[tau] = the tuple's total quantity); the step played in it reads the agents' greedy actions from
 //     the per-row bytes instead of G[tau]; every other step is the plain chain step.  The row windows cover the
 //     prices of every tuple for every intercept in [0.7a, a].
+//   * per-game sweeps (template SWEEP, compiled with NOISE): gamma / alpha / epsilon schedule / noise_prob per game.
 #pragma once
 #include <type_traits>
 #include "thrl_kernels.h"
@@ -173,7 +174,7 @@ __device__ __forceinline__ void replay_step(uint32_t xw, const Ops<QT>& xo, unsi
     __builtin_amdgcn_wave_barrier();
 }
 
-template <typename QT, int N, int NSEG, bool NOISE>
+template <typename QT, int N, int NSEG, bool NOISE, bool SWEEP>
 __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -229,6 +230,29 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         const uint64_t gid = a.game_offset + (uint64_t)g;
         QT* __restrict__ qg = reinterpret_cast<QT*>(a.q) + (int64_t)g * a.stride;
         const double price0 = a.state[g];
+        // SWEEP: this game's own gamma / alpha / epsilon schedule / noise_prob (thrl_buffers.sweep_*: the reference's research
+        // loop is configs x runs; here a config is a game), derived exactly as fill_agents() derives the scalars
+        TdCoef tcs[N];
+        double epsg[N];
+        double np_g = a.env.noise_prob;
+        QT alpha_g = alpha_me, gamma_g = gamma_me, ag_g = ag_me;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            tcs[i] = td_coef(a.ag[i]);
+            epsg[i] = 0.0;
+            if (SWEEP) {
+                const size_t k = (size_t)i * (size_t)a.G + (size_t)g;
+                const double al = a.sw_alpha ? a.sw_alpha[k] : a.ag[i].alpha, ga = a.sw_gamma ? a.sw_gamma[k] : a.ag[i].gamma;
+                tcs[i] = td_coef(al, ga);
+                epsg[i] = a.sw_eps ? a.sw_eps[k] : a.eps[0][i];
+                if (my_ag == i) {
+                    alpha_g = std::is_same<QT, float>::value ? (QT)tcs[i].alpha_f : (QT)tcs[i].alpha;
+                    gamma_g = (QT)ga;
+                    ag_g = std::is_same<QT, float>::value ? (QT)tcs[i].alpha_gamma_f : (QT)0;
+                }
+            }
+        }
+        if (SWEEP && a.sw_noise_prob && a.env.noise_prob > 0.0) np_g = a.sw_noise_prob[g];     // (as the generic kernel: a sweep of a noisy env)
 
         // ---- tables -> LDS (window rows are contiguous in HBM), initial state -> local rows (window or spill)
         int init_play[N], init_train[N], spill_p[N], spill_t[N];
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         u = u01_32((i & 1) ? x.z : x.x);
                         ch = __umulhi((i & 1) ? x.w : x.y, (uint32_t)p.n_actions);
                     }
-                    if (u < a.eps[e][i]) mw |= 0xFFu << (8 * i);
+                    if (u < ((SWEEP && a.sw_eps) ? epsg[i] : a.eps[e][i])) mw |= 0xFFu << (8 * i);
                     cw |= ch << (8 * i);
                 }
                 Mw[seg] = mw; Cw[seg] = cw;
@@ -352,7 +376,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         nu = u01_32(xn.x);
                         na = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
                     }
-                    nzm[seg] = __ballot(seg * 64 + lane < T && nu < a.env.noise_prob);
+                    nzm[seg] = __ballot(seg * 64 + lane < T && nu < (SWEEP ? np_g : a.env.noise_prob));
                     NA[seg] = na;
                 }
             }
@@ -464,7 +488,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     const double aq = lut_aq[i * 64 + act];
                     const double re = __dmul_rn(price, aq);                       // environments.py:33
                     const QT ov = tabs[a.tab_off[i] + cell];
-                    ops[seg][i].set(ov, re, td_coef(p));
+                    ops[seg][i].set(ov, re, SWEEP ? tcs[i] : td_coef(p));
                     word[seg][i] = ns | (cell << 8);
                     if (valid) { lr[i] += re; la[i] += lut_sct[i * 64 + act]; }
                     // visit counter of the transition (agents.py:76), lane-parallel (the replay keeps only what is serial)
@@ -493,7 +517,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     }
                     const int nb = min(16, T - base_t);
                     const bool cnt = false;                   // (counted lane-parallel in phase (e))
-#define THRL_TUP_STEP(J) if ((J) < nb) replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cnt, ag_me, alpha_me, gamma_me);
+#define THRL_TUP_STEP(J) if ((J) < nb) replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cnt, SWEEP ? ag_g : ag_me, SWEEP ? alpha_g : alpha_me, SWEEP ? gamma_g : gamma_me);
                     THRL_TUP_STEP(0) THRL_TUP_STEP(1) THRL_TUP_STEP(2) THRL_TUP_STEP(3) THRL_TUP_STEP(4) THRL_TUP_STEP(5) THRL_TUP_STEP(6) THRL_TUP_STEP(7)
                     THRL_TUP_STEP(8) THRL_TUP_STEP(9) THRL_TUP_STEP(10) THRL_TUP_STEP(11) THRL_TUP_STEP(12) THRL_TUP_STEP(13) THRL_TUP_STEP(14) THRL_TUP_STEP(15)
 #undef THRL_TUP_STEP
@@ -515,6 +539,19 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     for (int r = 0; r < 4; r++) if ((e >> 3) == r) accd[r] += v;
                 }
             }
+            if (SWEEP) {                      // epsilon decays after every train_net call (agents.py:78), per game
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const size_t k = (size_t)i * (size_t)a.G + (size_t)g;
+                    const double eend = a.sw_eps_end ? a.sw_eps_end[k] : a.ag[i].eps_end;
+                    const double estep = a.sw_eps_step ? a.sw_eps_step[k] : a.ag[i].eps_step;
+                    epsg[i] = __dadd_rn(eend, __dmul_rn(__dsub_rn(epsg[i], eend), estep));
+                }
+            }
+        }
+        if (SWEEP && a.sw_eps && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; i++) a.sw_eps[(size_t)i * (size_t)a.G + (size_t)g] = epsg[i];
         }
 
         // ---- tables back to HBM, env state, visit counters
@@ -561,12 +598,12 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     }
 }
 
-template <typename QT, int N, bool NOISE>
+template <typename QT, int N, bool NOISE, bool SWEEP>
 static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
 #define THRL_TUP_LAUNCH(NS)                                                                                          \
     {                                                                                                                \
-        auto kern = k_tuple_episodes<QT, N, NS, NOISE>;                                                              \
+        auto kern = k_tuple_episodes<QT, N, NS, NOISE, SWEEP>;                                                       \
         if (lds > 64 * 1024) {                                                                                       \
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
@@ -581,13 +618,13 @@ static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, h
 #undef THRL_TUP_LAUNCH
 }
 
-template <typename QT, bool NOISE>
+template <typename QT, bool NOISE, bool SWEEP>
 static int launch_tuple_t(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     switch (a.N) {
-        case 1: return launch_tuple_n<QT, 1, NOISE>(a, grid, block, lds, s);
-        case 2: return launch_tuple_n<QT, 2, NOISE>(a, grid, block, lds, s);
-        case 3: return launch_tuple_n<QT, 3, NOISE>(a, grid, block, lds, s);
-        case 4: return launch_tuple_n<QT, 4, NOISE>(a, grid, block, lds, s);
+        case 1: return launch_tuple_n<QT, 1, NOISE, SWEEP>(a, grid, block, lds, s);
+        case 2: return launch_tuple_n<QT, 2, NOISE, SWEEP>(a, grid, block, lds, s);
+        case 3: return launch_tuple_n<QT, 3, NOISE, SWEEP>(a, grid, block, lds, s);
+        case 4: return launch_tuple_n<QT, 4, NOISE, SWEEP>(a, grid, block, lds, s);
     }
     return -1;
 }
