@@ -4,6 +4,7 @@
 #include <math.h>
 
 #include "thrl_policy.h"
+#include <type_traits>
 #include "thrl_kernels.h"
 
 namespace thrl {
@@ -78,7 +79,7 @@ __device__ __forceinline__ int train_xs_len(int N) { return (N + kChunk - 1) / k
 // its row sums drive the critic (d loss/d v_i = -(2/N^2)(R + N c_i), c_i = gamma*v'_i - v_i, v' not
 // detached) and its column sums the actor (weight r_j + C/N in place of Reinforce's return).
 template <int kPad, bool AC>
-__global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_nn_reinforce_train(int G, int A, float* __restrict__ params,
         float* __restrict__ adam_m, float* __restrict__ adam_v, int step, int N, int ld,
         const double* __restrict__ price, const int32_t* __restrict__ action, const double* __restrict__ reward,
         const double* __restrict__ nprice, float gamma, float ent_coef, float lr,
@@ -331,46 +332,112 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         }
         {   // ---- pass A1: logits (without bias) into dz
             // plain: thread = (state quad tid>>2 of 64, action group tid&3), all 256 hidden units;
-            // sliced: thread = (state quad tid&15 of 16, action group (tid>>4)&3, hidden-unit slice tid>>6),
-            //         partial logits to dz[slice][state][k], summed in pass A2
+            // sliced: thread = (state group tid&15 of 16, action group (tid>>4)&3, hidden-unit slice tid>>6),
+            //         partial logits to dz[slice][state][k], summed in pass A2.  A group is ceil(chunk / 16) states: 4 for a
+            //         full chunk, 3 for the 41 prices two Reinforce agents on one grid meet (a quarter of the FMAs saved),
+            //         fewer late in training when the policies have concentrated
             const int qq = sliced ? (tid & 15) : q, kk = sliced ? ((tid >> 4) & 3) : kg;
             const int j0 = sliced ? (tid >> 6) * (kH / 4) : 0, j1 = sliced ? j0 + kH / 4 : kH;
-            const f4 x4 = *reinterpret_cast<const f4*>(xa + c0 + 4 * qq);
-            f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // states 0..3 of the quad, kGp action pairs each
-#pragma unroll
-            for (int p = 0; p < kGp; p++) { za[p] = zb[p] = zc[p] = zd[p] = f2{0.0f, 0.0f}; }
             const float* wrow = W2t + 2 * kGp * kk;
-#pragma unroll 4
-            for (int j = j0; j < j1; j++) {
-                const float w1 = w1s[j], b1 = b1s[j];
-                const float h0 = fmaxf(__fmaf_rn(w1, x4.x, b1), 0.0f), h1 = fmaxf(__fmaf_rn(w1, x4.y, b1), 0.0f);
-                const float h2 = fmaxf(__fmaf_rn(w1, x4.z, b1), 0.0f), h3 = fmaxf(__fmaf_rn(w1, x4.w, b1), 0.0f);
+            float* obase = dz + (sliced ? (tid >> 6) * 64 * kPad : 0) + 2 * kGp * kk;
+            auto a1 = [&](auto s_tag) {
+                constexpr int S = decltype(s_tag)::value;
+                float x[S];
+                f2 z[S][kGp];
 #pragma unroll
-                for (int p = 0; p < kGp; p++) {
-                    const f2 wv = *reinterpret_cast<const f2*>(wrow + j * kPad + 2 * p);
-                    za[p] = pk_fma(wv, f2{h0, h0}, za[p]); zb[p] = pk_fma(wv, f2{h1, h1}, zb[p]);
-                    zc[p] = pk_fma(wv, f2{h2, h2}, zc[p]); zd[p] = pk_fma(wv, f2{h3, h3}, zd[p]);
+                for (int u = 0; u < S; u++) {
+                    x[u] = xa[c0 + S * qq + u];
+#pragma unroll
+                    for (int p = 0; p < kGp; p++) z[u][p] = f2{0.0f, 0.0f};
                 }
-            }
-            float* o = dz + (sliced ? (tid >> 6) * 64 * kPad : 0) + (4 * qq) * kPad + 2 * kGp * kk;
+#pragma unroll 4
+                for (int j = j0; j < j1; j++) {
+                    const float w1 = w1s[j], b1 = b1s[j];
+                    float h[S];
 #pragma unroll
-            for (int p = 0; p < kGp; p++) {
-                *reinterpret_cast<f2*>(o + 2 * p) = za[p];
-                *reinterpret_cast<f2*>(o + kPad + 2 * p) = zb[p];
-                *reinterpret_cast<f2*>(o + 2 * kPad + 2 * p) = zc[p];
-                *reinterpret_cast<f2*>(o + 3 * kPad + 2 * p) = zd[p];
-            }
+                    for (int u = 0; u < S; u++) h[u] = fmaxf(__fmaf_rn(w1, x[u], b1), 0.0f);
+#pragma unroll
+                    for (int p = 0; p < kGp; p++) {
+                        const f2 wv = *reinterpret_cast<const f2*>(wrow + j * kPad + 2 * p);
+#pragma unroll
+                        for (int u = 0; u < S; u++) z[u][p] = pk_fma(wv, f2{h[u], h[u]}, z[u][p]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < S; u++)
+#pragma unroll
+                    for (int p = 0; p < kGp; p++) *reinterpret_cast<f2*>(obase + (S * qq + u) * kPad + 2 * p) = z[u][p];
+            };
+            if (!sliced || cn > 48) a1(std::integral_constant<int, 4>{});
+            else if (cn > 32) a1(std::integral_constant<int, 3>{});
+            else if (cn > 16) a1(std::integral_constant<int, 2>{});
+            else a1(std::integral_constant<int, 1>{});
         }
         __syncthreads();
-        // ---- pass A2 (thread = transition): softmax, entropy, d loss / d logits
-        if (tid < cn) {
+        // ---- pass A2: softmax, entropy, d loss / d logits.  Folded: FOUR THREADS PER STATE (a quarter of the actions each,
+        // quad reductions by DPP), so all four waves work -- with thread = state one wave did the 21 exp / log / divide chains
+        // of 64 states while three waited: a fifth of the passes' time.  Plain: thread = transition.
+        if (sliced && (tid >> 6) * 16 >= cn) {
+            // (this wave's sixteen states are all beyond the chunk)
+        } else if (sliced) {
+            constexpr int kQ = kPad / 4;
+            const int st = tid >> 2, part = tid & 3;
+            const bool live = st < cn;
+            float zz[kQ], lp[kQ];
+#pragma unroll
+            for (int p2 = 0; p2 < kQ / 2; p2++) {
+                f2 v = *reinterpret_cast<const f2*>(dz + st * kPad + kQ * part + 2 * p2);
+                for (int sl = 1; sl < 4; sl++) v += *reinterpret_cast<const f2*>(dz + (sl * 64 + st) * kPad + kQ * part + 2 * p2);   // slices in order
+                zz[2 * p2] = v.x; zz[2 * p2 + 1] = v.y;
+            }
+            auto quad_max = [](float v) {
+                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+                return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+            };
+            auto quad_sum = [](float v) {
+                v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+                return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+            };
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < kQ; i++) if (kQ * part + i < A) { zz[i] += b2s[kQ * part + i]; m = fmaxf(m, zz[i]); }
+            m = quad_max(m);
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kQ; i++) if (kQ * part + i < A) { zz[i] = expf(zz[i] - m); sum += zz[i]; }
+            sum = quad_sum(sum);
+            float Hn = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kQ; i++) {
+                lp[i] = 0.0f;
+                if (kQ * part + i < A) {
+                    zz[i] = zz[i] / sum;
+                    lp[i] = logf(fminf(fmaxf(zz[i], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
+                    Hn -= zz[i] * lp[i];
+                }
+            }
+            Hn = quad_sum(Hn);
+            const long long* row = sga + st * kPad + kQ * part;
+            long long rk[kQ], sg = 0;
+#pragma unroll
+            for (int i = 0; i < kQ; i++) { rk[i] = kQ * part + i < A ? row[i] : 0; sg += rk[i]; }
+            sg += __shfl_xor(sg, 1, 64);
+            sg += __shfl_xor(sg, 2, 64);
+            const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[st];
+#pragma unroll
+            for (int i = 0; i < kQ; i++)
+                zz[i] = kQ * part + i < A ? (zz[i] * SG - (float)((double)rk[i] * 0x1p-40) + cnt * (ent_coef * zz[i] * (lp[i] + Hn))) * invN : 0.0f;
+            if (live) {
+#pragma unroll
+                for (int p2 = 0; p2 < kQ / 2; p2++)
+                    *reinterpret_cast<f2*>(dz + st * kPad + kQ * part + 2 * p2) = f2{zz[2 * p2], zz[2 * p2 + 1]};
+            }
+        } else if (tid < cn) {
             const int n = c0 + tid;
             float zz[kPad];
 #pragma unroll
             for (int k4 = 0; k4 < kPad / 4; k4++) {
-                f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
-                if (sliced)                                 // add the other three hidden-unit slices, in order
-                    for (int sl = 1; sl < 4; sl++) v += *reinterpret_cast<const f4*>(dz + (sl * 64 + tid) * kPad + 4 * k4);
+                const f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
                 zz[4 * k4] = v.x; zz[4 * k4 + 1] = v.y; zz[4 * k4 + 2] = v.z; zz[4 * k4 + 3] = v.w;
             }
             float m = -INFINITY;
@@ -388,23 +455,11 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
                     lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
                     Hn -= zz[k] * lp[k];
                 }
-            if (!AC && U > 0) {                            // folded over the transitions of state c0 + tid
-                const long long* row = sga + tid * kPad;
-                long long sg = 0;
+            const int a_n = action[n];
+            const float Gn = Gs[n];
 #pragma unroll
-                for (int k = 0; k < kPad; k++) if (k < A) sg += row[k];
-                const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[tid];
-#pragma unroll
-                for (int k = 0; k < kPad; k++)
-                    zz[k] = k < A ? (zz[k] * SG - (float)((double)row[k] * 0x1p-40) + cnt * (ent_coef * zz[k] * (lp[k] + Hn))) * invN
-                                  : 0.0f;
-            } else {
-                const int a_n = action[n];
-                const float Gn = Gs[n];
-#pragma unroll
-                for (int k = 0; k < kPad; k++)
-                    zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
-            }
+            for (int k = 0; k < kPad; k++)
+                zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
 #pragma unroll
             for (int k4 = 0; k4 < kPad / 4; k4++)
                 *reinterpret_cast<f4*>(dz + tid * kPad + 4 * k4) = f4{zz[4 * k4], zz[4 * k4 + 1], zz[4 * k4 + 2], zz[4 * k4 + 3]};
@@ -481,6 +536,22 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
         for (int part = 0; part < 8; part++) gb2 += gb2s[part * 32 + tid];
     }
 
+    // Adam state of the first sweep iteration: requested here, so the HBM round trip overlaps the norm reduction and the
+    // staging of the gradient below
+    constexpr int kB = 12;
+    constexpr bool kAdamPrefetch = true;
+    float* mg = adam_m + (int64_t)g * P;
+    float* vg = adam_v + (int64_t)g * P;
+    float mm[kB], vv[kB], ww[kB];
+    auto load_state = [&](int i0) {
+#pragma unroll
+        for (int b = 0; b < kB; b++) {
+            const int idx = min(i0 + 256 * b, P - 1);
+            mm[b] = mg[idx]; vv[b] = vg[idx]; ww[b] = w[idx];
+        }
+    };
+    if (kAdamPrefetch) load_state(tid);
+
     // clip_grad_norm_(1.0) (agents.py:192)
     float sq = 0.0f;
     if (half == 0) {
@@ -500,8 +571,6 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     const float t = (float)(step + 1);
     const float bc1 = 1.0f - powf(0.9f, t), bc2s = sqrtf(1.0f - powf(0.999f, t));
     const float step_size = lr / bc1;
-    float* mg = adam_m + (int64_t)g * P;
-    float* vg = adam_v + (int64_t)g * P;
     float* gl = comb + 128 * kRow + 256;                    // [P] unscaled gradient (behind the combine scratch)
     if (half == 0) {
         gl[ja] = gw1a; gl[jb] = gw1b; gl[kH + ja] = gb1a; gl[kH + jb] = gb1b;
@@ -515,14 +584,11 @@ __global__ void __launch_bounds__(256) k_nn_reinforce_train(int G, int A, float*
     if (tid < A) gl[2 * kH + A * kH + tid] = gb2;
     if (AC && tid == 255) gl[Pp + kH] = gbv;
     __syncthreads();
-    constexpr int kB = 12;
     for (int i0 = tid; i0 < P; i0 += 256 * kB) {
-        float mm[kB], vv[kB], ww[kB], gg[kB];
+        float gg[kB];
+        if (!kAdamPrefetch || i0 != tid) load_state(i0);
 #pragma unroll
-        for (int b = 0; b < kB; b++) {
-            const int idx = min(i0 + 256 * b, P - 1);
-            mm[b] = mg[idx]; vv[b] = vg[idx]; ww[b] = w[idx]; gg[b] = gl[idx];
-        }
+        for (int b = 0; b < kB; b++) gg[b] = gl[min(i0 + 256 * b, P - 1)];
 #pragma unroll
         for (int b = 0; b < kB; b++) {
             const int idx = i0 + 256 * b;
