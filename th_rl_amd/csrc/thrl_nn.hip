@@ -66,8 +66,9 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
 // Rows of fc_pi^T and of dz are padded to kPad = 24 or 32 floats (zero) for aligned vector LDS reads.
 constexpr int kChunk = 256;
 constexpr int kUmax = 64;          // state folding: distinct states handled per chunk
-constexpr int kUfold = 320;        // ... and per update (beyond that: the plain per-transition path)
-constexpr int kHash = 512;         // slots of the LDS table that finds them
+constexpr int kUfold = 448;        // ... and per update (beyond that: the plain per-transition path); 21 x 21 action pairs = 441 prices
+constexpr int kHash = 1024;        // slots of the LDS table that finds them (overlaid on dz: dead before the passes start)
+constexpr int kXu = 512;           // the distinct states, zero padded to whole chunks
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -102,12 +103,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* wvs = gvs + (AC ? NX : 0);                       // [kH]  fc_v.weight            (AC only)
     // Reinforce only: state dedupe (see below)
     unsigned short* uid = reinterpret_cast<unsigned short*>(red + 8);   // [NX]  index of the transition's distinct state
-    float* xu = reinterpret_cast<float*>(uid + NX);         // [kHash] the distinct states in ascending order, zero padded
-    int* ucnt = reinterpret_cast<int*>(xu + kHash);         // [kUmax] transitions per state of the current chunk
+    float* xu = reinterpret_cast<float*>(uid + NX);         // [kXu] the distinct states in ascending order, zero padded
+    int* ucnt = reinterpret_cast<int*>(xu + kXu);           // [kUmax] transitions per state of the current chunk
     int* redi = ucnt + kUmax;                               // [8]
-    unsigned* hkeys = reinterpret_cast<unsigned*>(redi + 8);   // [kHash] hash table of the distinct states (float bits)
+    long long* sga = reinterpret_cast<long long*>(redi + 8);   // [kUmax][kPad] returns by (state, action) of the chunk, 2^-40 fixed point
+    // the hash table lives inside dz (8 KB in; the first 2 KB hold the packed keys): nothing else uses dz until the passes
+    unsigned* hkeys = reinterpret_cast<unsigned*>(dz) + 2048;  // [kHash] hash table of the distinct states (float bits)
     unsigned short* hrank = reinterpret_cast<unsigned short*>(hkeys + kHash);   // [kHash] slot -> index of the state
-    long long* sga = reinterpret_cast<long long*>(hrank + kHash);   // [kUmax][kPad] returns by (state, action) of the chunk, 2^-40 fixed point
+    static_assert((2048 + kHash) * 4 + kHash * 2 <= kChunk * 24 * 4 && kUfold <= 512, "hash table fits inside dz");
+    // (dz words 0-511: packed keys, padded to 512 for the sort; words 1024-1279: their ranks as u16)
     const int g = blockIdx.x, tid = threadIdx.x;
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
@@ -200,12 +204,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 xq[q2] = n < N ? xs[n] : 0.0f;
                 if (n < N) open_mask |= 1u << q2;
             }
-            xu[tid] = 0.0f; xu[tid + 256] = 0.0f;
+            for (int k = tid; k < kXu; k += 256) xu[k] = 0.0f;
             // distinct states by open addressing in a kHash-slot LDS table (key = the float32 state's
             // bits), then numbered by ascending key so the numbering -- and with it the order of
             // every later sum -- does not depend on which thread won which slot
             constexpr unsigned kEmpty = 0xFFFFFFFFu;
-            hkeys[tid] = kEmpty; hkeys[tid + 256] = kEmpty;
+            constexpr int kParts = kHash / 256;
+#pragma unroll
+            for (int r = 0; r < kParts; r++) hkeys[tid + 256 * r] = kEmpty;
             if (tid < 8) redi[tid] = 0;
             __syncthreads();
             int myslot[kOwn];
@@ -215,7 +221,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 myslot[q2] = 0;
                 if ((open_mask >> q2) & 1u) {
                     const unsigned bits = __float_as_uint(xq[q2]);
-                    unsigned h = (bits * 2654435761u) >> 23;
+                    unsigned h = (bits * 2654435761u) >> 22;
                     int probe = 0;
                     for (; probe < kHash; probe++) {
                         if (redi[5] > kUfold) { probe = kHash; break; }      // too many states already: plain path
@@ -229,36 +235,79 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
             __syncthreads();
-            const unsigned key_a = hkeys[tid], key_b = hkeys[tid + 256];
-            const unsigned long long occ_a = __ballot(key_a != kEmpty), occ_b = __ballot(key_b != kEmpty);
-            if ((tid & 63) == 0) { ucnt[tid >> 6] = __popcll(occ_a); ucnt[4 + (tid >> 6)] = __popcll(occ_b); }
+            unsigned key[kParts];
+            unsigned long long occ[kParts];
+#pragma unroll
+            for (int r = 0; r < kParts; r++) {
+                key[r] = hkeys[tid + 256 * r];
+                occ[r] = __ballot(key[r] != kEmpty);
+                if ((tid & 63) == 0) ucnt[4 * r + (tid >> 6)] = __popcll(occ[r]);
+            }
             if (lost) redi[4] = 1;
             __syncthreads();
-            int n_states = 0, before_a = 0, before_b = 0;
+            // exclusive prefix of the 4 kParts per-wave counts: lane l < 16 holds count l, scanned across the lanes
+            int n_states, before[kParts];
+            {
+                const int lane = tid & 63;
+                int c = lane < 4 * kParts ? ucnt[lane] : 0, inc = c;
 #pragma unroll
-            for (int wv = 0; wv < 8; wv++) {
-                const int c = ucnt[wv];
-                if (wv < (tid >> 6)) before_a += c;
-                if (wv < 4 + (tid >> 6)) before_b += c;
-                n_states += c;
+                for (int d = 1; d < 4 * kParts; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+                n_states = __shfl(inc, 4 * kParts - 1, 64);
+#pragma unroll
+                for (int r = 0; r < kParts; r++) before[r] = __shfl(inc - c, 4 * r + (tid >> 6), 64);
             }
-            // fold only where it is cheaper: ~5 units per 64 states against ~16 per 256 transitions
-            const bool pays = ((n_states + 63) / 64) * 5 + 2 < ((N + kChunk - 1) / kChunk) * 16;
-            U = (redi[4] != 0 || n_states > kUfold || !pays) ? 0 : n_states;
+            // (the folded update costs O((states + 256) * A): it always pays)
+            U = (redi[4] != 0 || n_states > kUfold) ? 0 : n_states;
             if (U > 0) {
                 // keys packed densely (in slot order), then ranked by value over the U of them
                 unsigned* dense = reinterpret_cast<unsigned*>(dz);
                 const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
-                if (key_a != kEmpty) dense[before_a + __popcll(occ_a & lt)] = key_a;
-                if (key_b != kEmpty) dense[before_b + __popcll(occ_b & lt)] = key_b;
-                __syncthreads();
-                int ra = 0, rb = 0;
-                for (int j = 0; j < U; j++) {
-                    const unsigned kj = dense[j];
-                    ra += kj < key_a ? 1 : 0; rb += kj < key_b ? 1 : 0;
+                unsigned short* rankd = reinterpret_cast<unsigned short*>(dense + 1024);      // [kUfold] rank of packed key i
+                int di[kParts];
+#pragma unroll
+                for (int r = 0; r < kParts; r++) {
+                    di[r] = before[r] + __popcll(occ[r] & lt);
+                    if (key[r] != kEmpty) dense[di[r]] = key[r];
                 }
-                if (key_a != kEmpty) { hrank[tid] = (unsigned short)ra; xu[ra] = __uint_as_float(key_a); }
-                if (key_b != kEmpty) { hrank[tid + 256] = (unsigned short)rb; xu[rb] = __uint_as_float(key_b); }
+                if (U <= 96) {
+                    // few states (two policies on one grid: 41): thread i < U counts the keys below packed key i -- two waves at most
+                    __syncthreads();
+                    if (tid < U) {
+                        const unsigned mine = dense[tid];
+                        int rank = 0;
+                        for (int j = 0; j < U; j++) rank += dense[j] < mine ? 1 : 0;
+                        rankd[tid] = (unsigned short)rank;
+                        xu[rank] = __uint_as_float(mine);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < kParts; r++)
+                        if (key[r] != kEmpty) hrank[tid + 256 * r] = rankd[di[r]];
+                } else {
+                    // many states (a QTable opponent: up to 441 prices): bitonic sort of the packed keys, ranks by binary search
+                    int n2 = 128;
+                    while (n2 < U) n2 <<= 1;                               // <= 512 = 2 x 256 threads
+                    for (int k = U + tid; k < n2; k += 256) dense[k] = kEmpty;
+                    __syncthreads();
+                    for (int k = 2; k <= n2; k <<= 1)
+                        for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
+                            if (tid < (n2 >> 1)) {
+                                const int lo_i = ((tid & ~(j2 - 1)) << 1) | (tid & (j2 - 1)), hi_i = lo_i | j2;
+                                const unsigned a = dense[lo_i], b = dense[hi_i];
+                                const bool up = (lo_i & k) == 0;
+                                if ((a > b) == up) { dense[lo_i] = b; dense[hi_i] = a; }
+                            }
+                            __syncthreads();
+                        }
+                    for (int k = tid; k < U; k += 256) xu[k] = __uint_as_float(dense[k]);
+#pragma unroll
+                    for (int r = 0; r < kParts; r++)
+                        if (key[r] != kEmpty) {
+                            int lo = 0, hi = U;                            // first index with dense[i] >= key (it is there)
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (dense[mid] < key[r]) lo = mid + 1; else hi = mid; }
+                            hrank[tid + 256 * r] = (unsigned short)lo;
+                        }
+                }
                 __syncthreads();
 #pragma unroll
                 for (int q2 = 0; q2 < kOwn; q2++)
@@ -294,246 +343,385 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
 
     const float invN = 1.0f / (float)N;
-    // pass B ownership: hidden units ja = tid & 127 and jb = ja + 128, transitions of parity tid >> 7
-    const int ja = tid & 127, jb = ja + 128, half = tid >> 7;
-    f2 gWa[kPad / 2], gWb[kPad / 2], ca[kPad / 2], cb[kPad / 2];
+    float* comb = reinterpret_cast<float*>(smem_nn);        // [128][kPad * 2 + 4], over W2t / dz (once they are no longer needed)
+    constexpr int kRow = kPad * 2 + 6;
+    float* gl = comb + 128 * kRow + 256;                    // [P] unscaled gradient for the Adam sweep (behind the combine scratch)
+    float sq = 0.0f;                                        // this thread's share of |gradient|^2
+    if (!AC && U > 0) {
+        // ---- Folded update on the PIECEWISE-LINEAR form of the network.  The policy has ONE input (the price, agents.py:127-133:
+        // Linear(1, 256) -> relu -> Linear(256, A)), so unit j is active on a half line of prices: with the distinct states
+        // sorted (xu ascending) its active states are a suffix (w1 > 0) or a prefix (w1 < 0) starting / ending at a threshold
+        // index t_j -- found by binary search with the SAME test the direct evaluation uses (fma(w1, x, b1) > 0, monotonic in x).
+        //   forward   z_k(x_s) = b2_k + x_s * A_k(s) + B_k(s),  A_k(s) = sum over the units active at s of W2[k][j] * w1_j,
+        //             B_k likewise with b1_j: every unit adds its 2 x A terms ONCE, at its threshold, into per-state buckets;
+        //             a running sum over the sorted states gives A, B per state.
+        //   backward  d W2[k][j] = w1_j * S1_j[k] + b1_j * S0_j[k],  d w1_j = sum_k W2[k][j] S1_j[k],  d b1_j = sum_k W2[k][j] S0_j[k],
+        //             S0_j[k] = sum of d_s[k] over j's active states, S1_j[k] = the same of d_s[k] * x_s: range sums of two
+        //             prefix arrays over the sorted states.
+        // O((U + 256) * A) operations instead of O(U * 256 * A).  All sums are integers in 2^-40 fixed point (LDS integer
+        // atomics: order independent, deterministic; range sums are exact differences), combined in float64 at the end.
+        constexpr double kFix = 1099511627776.0, kUnfix = 0x1p-40;
+        typedef unsigned long long u64;
+        long long* EA = reinterpret_cast<long long*>(dz);   // [kUmax][kPad]  buckets -> A per state -> d -> prefix of d
+        long long* EB = EA + kUmax * kPad;                  // [kUmax][kPad]  ... B ... d * x
+        static_assert(kChunk * kPad * sizeof(float) == 2 * kUmax * kPad * sizeof(long long), "EA / EB overlay dz exactly");
+        const float w1 = w1s[tid], b1 = b1s[tid];           // this thread's hidden unit: j = tid
+        float wr[kPad];
 #pragma unroll
-    for (int p = 0; p < kPad / 2; p++) {
-        gWa[p] = f2{0.0f, 0.0f}; gWb[p] = f2{0.0f, 0.0f};
-        ca[p] = *reinterpret_cast<const f2*>(W2t + ja * kPad + 2 * p);
-        cb[p] = *reinterpret_cast<const f2*>(W2t + jb * kPad + 2 * p);
-    }
-    float gw1a = 0.0f, gb1a = 0.0f, gw1b = 0.0f, gb1b = 0.0f, gb2 = 0.0f, gwva = 0.0f, gwvb = 0.0f;
-    const float w1a = w1s[ja], b1a = b1s[ja], w1b = w1s[jb], b1b = b1s[jb];
-    // pass A1 ownership: transitions 4q..4q+3 of the chunk, actions kPad/4 * kg .. (6 or 8 of them)
-    constexpr int kGp = kPad / 8;                           // action pairs per thread
-    const int q = tid >> 2, kg = tid & 3;
-
-    const float* xa = U > 0 ? xu : xs;                      // the states the passes run over
-    const int NN = U > 0 ? U : N;
-    const int cstep = U > 0 ? kUmax : kChunk;               // folded: 64 states per chunk; plain: 256 transitions
-    for (int c0 = 0; c0 < NN; c0 += cstep) {
-        const int cn = min(cstep, NN - c0);
-        const bool sliced = U > 0;                  // 64 states: split the hidden units over the 4 waves instead
-        if (!AC && U > 0) {
-            // returns of this chunk's states by (state, action), and their transition counts
-            if (tid < kUmax) ucnt[tid] = 0;
+        for (int p = 0; p < kPad / 2; p++) {
+            const f2 v = *reinterpret_cast<const f2*>(W2t + tid * kPad + 2 * p);
+            wr[2 * p] = v.x; wr[2 * p + 1] = v.y;
+        }
+        const bool pos = !(w1 < 0.0f);                      // active states: [t, U) if pos, [0, t) otherwise
+        int t;
+        {
+            int lo = 0, hi = U;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const bool act = __fmaf_rn(w1, xu[mid], b1) > 0.0f;
+                if (act == pos) hi = mid; else lo = mid + 1;
+            }
+            t = lo;
+        }
+        constexpr int kBaseParts = 256 / kPad;
+        int* in_base = reinterpret_cast<int*>(xs);          // [kH] (the per-transition states are no longer needed: uid has their index)
+        in_base[tid] = (pos && t == 0) || (!pos && t > 0);  // (read after the chunk loop's first barrier)
+        long long S0[kPad], S1[kPad];
+#pragma unroll
+        for (int k = 0; k < kPad; k++) { S0[k] = 0; S1[k] = 0; }
+        long long run = 0, gb2i = 0;                        // threads < 2 kPad: running A_k / B_k; threads < kPad: sum of d_s[k]
+        constexpr int kQ = kPad / 4;
+        auto quad_max = [](float v) {
+            v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
+            return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
+        };
+        auto quad_sum = [](float v) {
+            v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+            return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+        };
+        for (int c0 = 0; c0 < U; c0 += kUmax) {
+            const int cn = min(kUmax, U - c0);
+            for (int k = tid; k < 2 * kUmax * kPad; k += 256) EA[k] = 0;
             for (int k = tid; k < kUmax * kPad; k += 256) sga[k] = 0;
+            if (tid < kUmax) ucnt[tid] = 0;
             __syncthreads();
+            {   // a unit whose threshold lies strictly inside the state range enters (or leaves) the running sums there: few
+                // units per bucket.  (The operands pass through an empty asm so that the 2 x A conversions are not hoisted out of
+                // the chunk loop as loop invariants: 96 registers.)
+                const int rel = t - c0;
+                if (t > 0 && t < U && rel >= 0 && rel < kUmax) {
+                    float w1v = w1, b1v = b1;
+                    asm volatile("" : "+v"(w1v), "+v"(b1v));
+#pragma unroll
+                    for (int k = 0; k < kPad; k++)
+                        if (k < A) {
+                            const long long ia = llrint((double)wr[k] * (double)w1v * kFix), ib = llrint((double)wr[k] * (double)b1v * kFix);
+                            atomicAdd(reinterpret_cast<u64*>(&EA[rel * kPad + k]), (u64)(pos ? ia : -ia));
+                            atomicAdd(reinterpret_cast<u64*>(&EB[rel * kPad + k]), (u64)(pos ? ib : -ib));
+                        }
+                }
+            }
+            if (c0 == 0 && tid < kBaseParts * kPad) {
+                // the units that are active from the first state on (suffix units below the range, every prefix unit that is active
+                // at all) start the running sums: about half of all units, so they are summed by (action, part) threads instead
+                // of 256 x 2A atomics on the same 2A words
+                const int k = tid % kPad, part = tid / kPad;
+                long long sa = 0, sb = 0;
+                if (k < A)
+                    for (int j = part; j < kH; j += kBaseParts)
+                        if (in_base[j]) {
+                            const double wv = (double)W2t[j * kPad + k];
+                            sa += llrint(wv * (double)w1s[j] * kFix); sb += llrint(wv * (double)b1s[j] * kFix);
+                        }
+                atomicAdd(reinterpret_cast<u64*>(&EA[k]), (u64)sa);
+                atomicAdd(reinterpret_cast<u64*>(&EB[k]), (u64)sb);
+            }
+            // returns of this chunk's states by (state, action), and their transition counts
             for (int n = tid; n < N; n += 256) {
                 const int u = (int)uid[n] - c0;
                 if (u >= 0 && u < cn) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&sga[u * kPad + action[n]]),
-                              (unsigned long long)llrint((double)Gs[n] * 1099511627776.0));
+                    atomicAdd(reinterpret_cast<u64*>(&sga[u * kPad + action[n]]), (u64)llrint((double)Gs[n] * kFix));
                     atomicAdd(&ucnt[u], 1);
                 }
             }
             __syncthreads();
-        }
-        {   // ---- pass A1: logits (without bias) into dz
-            // plain: thread = (state quad tid>>2 of 64, action group tid&3), all 256 hidden units;
-            // sliced: thread = (state group tid&15 of 16, action group (tid>>4)&3, hidden-unit slice tid>>6),
-            //         partial logits to dz[slice][state][k], summed in pass A2.  A group is ceil(chunk / 16) states: 4 for a
-            //         full chunk, 3 for the 41 prices two Reinforce agents on one grid meet (a quarter of the FMAs saved),
-            //         fewer late in training when the policies have concentrated
-            const int qq = sliced ? (tid & 15) : q, kk = sliced ? ((tid >> 4) & 3) : kg;
-            const int j0 = sliced ? (tid >> 6) * (kH / 4) : 0, j1 = sliced ? j0 + kH / 4 : kH;
-            const float* wrow = W2t + 2 * kGp * kk;
-            float* obase = dz + (sliced ? (tid >> 6) * 64 * kPad : 0) + 2 * kGp * kk;
-            auto a1 = [&](auto s_tag) {
-                constexpr int S = decltype(s_tag)::value;
-                float x[S];
-                f2 z[S][kGp];
+            if (tid < 2 * kPad) {                           // running sums over the sorted states: A_k(s), B_k(s) in place
+                long long* arr = (tid < kPad ? EA : EB) + (tid < kPad ? tid : tid - kPad);
+                for (int s0 = 0; s0 < kUmax; s0 += 16) {
+                    long long v[16];
 #pragma unroll
-                for (int u = 0; u < S; u++) {
-                    x[u] = xa[c0 + S * qq + u];
+                    for (int u = 0; u < 16; u++) v[u] = arr[(s0 + u) * kPad];
 #pragma unroll
-                    for (int p = 0; p < kGp; p++) z[u][p] = f2{0.0f, 0.0f};
+                    for (int u = 0; u < 16; u++) { run += v[u]; arr[(s0 + u) * kPad] = run; }
                 }
-#pragma unroll 4
-                for (int j = j0; j < j1; j++) {
-                    const float w1 = w1s[j], b1 = b1s[j];
-                    float h[S];
+            }
+            __syncthreads();
+            // softmax, entropy, d loss / d logits folded over the transitions of each state: four threads per state
+            if ((tid >> 6) * 16 < cn) {
+                const int st = tid >> 2, part = tid & 3;
+                const bool live = st < cn;
+                const double x = (double)xu[c0 + st];
+                float zz[kQ], lp[kQ];
+                float m = -INFINITY;
 #pragma unroll
-                    for (int u = 0; u < S; u++) h[u] = fmaxf(__fmaf_rn(w1, x[u], b1), 0.0f);
+                for (int i = 0; i < kQ; i++) {
+                    const int k = kQ * part + i;
+                    zz[i] = 0.0f;
+                    if (k < A) {
+                        zz[i] = (float)(fma((double)EA[st * kPad + k] * kUnfix, x, (double)EB[st * kPad + k] * kUnfix) + (double)b2s[k]);
+                        m = fmaxf(m, zz[i]);
+                    }
+                }
+                m = quad_max(m);
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kQ; i++) if (kQ * part + i < A) { zz[i] = expf(zz[i] - m); sum += zz[i]; }
+                sum = quad_sum(sum);
+                float Hn = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kQ; i++) {
+                    lp[i] = 0.0f;
+                    if (kQ * part + i < A) {
+                        zz[i] = zz[i] / sum;
+                        lp[i] = logf(fminf(fmaxf(zz[i], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
+                        Hn -= zz[i] * lp[i];
+                    }
+                }
+                Hn = quad_sum(Hn);
+                const long long* row = sga + st * kPad + kQ * part;
+                long long rk[kQ], sg = 0;
+#pragma unroll
+                for (int i = 0; i < kQ; i++) { rk[i] = kQ * part + i < A ? row[i] : 0; sg += rk[i]; }
+                sg += __shfl_xor(sg, 1, 64);
+                sg += __shfl_xor(sg, 2, 64);
+                const float SG = (float)((double)sg * kUnfix), cnt = (float)ucnt[st];
+#pragma unroll
+                for (int i = 0; i < kQ; i++) {
+                    const int k = kQ * part + i;
+                    const float d = (k < A && live) ? (zz[i] * SG - (float)((double)rk[i] * kUnfix) + cnt * (ent_coef * zz[i] * (lp[i] + Hn))) * invN : 0.0f;
+                    EA[st * kPad + k] = llrint((double)d * kFix);
+                    EB[st * kPad + k] = llrint((double)d * x * kFix);
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * kPad) {                           // inclusive prefix of d_s[k] (EA) and d_s[k] * x_s (EB) over the chunk
+                long long* arr = (tid < kPad ? EA : EB) + (tid < kPad ? tid : tid - kPad);
+                long long acc = 0;
+                for (int s0 = 0; s0 < cn; s0 += 16) {       // (rows >= cn of the last 16 are stale: never read)
+                    long long v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) v[u] = arr[(s0 + u) * kPad];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) { acc += v[u]; arr[(s0 + u) * kPad] = acc; }
+                }
+                if (tid < kPad) gb2i += arr[(cn - 1) * kPad];
+            }
+            __syncthreads();
+            {   // this unit's range sums over the chunk
+                const int lo_s = pos ? max(t - c0, 0) : 0, hi_s = pos ? cn : min(t - c0, cn);
+                if (lo_s < hi_s) {
+                    const long long* h0 = EA + (hi_s - 1) * kPad;
+                    const long long* h1 = EB + (hi_s - 1) * kPad;
+                    const long long* l0 = EA + (lo_s > 0 ? lo_s - 1 : 0) * kPad;
+                    const long long* l1 = EB + (lo_s > 0 ? lo_s - 1 : 0) * kPad;
+#pragma unroll
+                    for (int k = 0; k < kPad; k++)
+                        if (k < A) {
+                            S0[k] += h0[k] - (lo_s > 0 ? l0[k] : 0);
+                            S1[k] += h1[k] - (lo_s > 0 ? l1[k] : 0);
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        // the gradient of this unit's parameters, straight into the sweep's staging area (EA / EB and W2t are dead: synced above)
+        double dw1 = 0.0, db1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kPad; k++)
+            if (k < A) {
+                const double s0 = (double)S0[k] * kUnfix, s1 = (double)S1[k] * kUnfix;
+                const float gw = (float)((double)w1 * s1 + (double)b1 * s0);
+                gl[2 * kH + k * kH + tid] = gw;
+                sq += gw * gw;
+                dw1 += (double)wr[k] * s1; db1 += (double)wr[k] * s0;
+            }
+        const float gw1 = (float)dw1, gb1 = (float)db1;
+        gl[tid] = gw1; gl[kH + tid] = gb1;
+        sq += gw1 * gw1 + gb1 * gb1;
+        if (tid < A) {
+            const float gb2 = (float)((double)gb2i * kUnfix);
+            gl[2 * kH + A * kH + tid] = gb2;
+            sq += gb2 * gb2;
+        }
+    } else {
+        // pass B ownership: hidden units ja = tid & 127 and jb = ja + 128, transitions of parity tid >> 7
+        const int ja = tid & 127, jb = ja + 128, half = tid >> 7;
+        f2 gWa[kPad / 2], gWb[kPad / 2], ca[kPad / 2], cb[kPad / 2];
+#pragma unroll
+        for (int p = 0; p < kPad / 2; p++) {
+            gWa[p] = f2{0.0f, 0.0f}; gWb[p] = f2{0.0f, 0.0f};
+            ca[p] = *reinterpret_cast<const f2*>(W2t + ja * kPad + 2 * p);
+            cb[p] = *reinterpret_cast<const f2*>(W2t + jb * kPad + 2 * p);
+        }
+        float gw1a = 0.0f, gb1a = 0.0f, gw1b = 0.0f, gb1b = 0.0f, gb2 = 0.0f, gwva = 0.0f, gwvb = 0.0f;
+        const float w1a = w1s[ja], b1a = b1s[ja], w1b = w1s[jb], b1b = b1s[jb];
+        // pass A1 ownership: transitions 4q..4q+3 of the chunk, actions kPad/4 * kg .. (6 or 8 of them)
+        constexpr int kGp = kPad / 8;                           // action pairs per thread
+        const int q = tid >> 2, kg = tid & 3;
+
+        const float* xa = xs;
+        for (int c0 = 0; c0 < N; c0 += kChunk) {                // 256 transitions per chunk
+            const int cn = min(kChunk, N - c0);
+            {   // ---- pass A1: logits (without bias) into dz: thread = (transition quad tid>>2 of 64, action group tid&3), all hidden units
+                const f4 x4 = *reinterpret_cast<const f4*>(xa + c0 + 4 * q);
+                f2 za[kGp], zb[kGp], zc[kGp], zd[kGp];          // transitions 0..3 of the quad, kGp action pairs each
+#pragma unroll
+                for (int p = 0; p < kGp; p++) { za[p] = zb[p] = zc[p] = zd[p] = f2{0.0f, 0.0f}; }
+                const float* wrow = W2t + 2 * kGp * kg;
+#pragma unroll 4
+                for (int j = 0; j < kH; j++) {
+                    const float w1 = w1s[j], b1 = b1s[j];
+                    const float h0 = fmaxf(__fmaf_rn(w1, x4.x, b1), 0.0f), h1 = fmaxf(__fmaf_rn(w1, x4.y, b1), 0.0f);
+                    const float h2 = fmaxf(__fmaf_rn(w1, x4.z, b1), 0.0f), h3 = fmaxf(__fmaf_rn(w1, x4.w, b1), 0.0f);
 #pragma unroll
                     for (int p = 0; p < kGp; p++) {
                         const f2 wv = *reinterpret_cast<const f2*>(wrow + j * kPad + 2 * p);
-#pragma unroll
-                        for (int u = 0; u < S; u++) z[u][p] = pk_fma(wv, f2{h[u], h[u]}, z[u][p]);
+                        za[p] = pk_fma(wv, f2{h0, h0}, za[p]); zb[p] = pk_fma(wv, f2{h1, h1}, zb[p]);
+                        zc[p] = pk_fma(wv, f2{h2, h2}, zc[p]); zd[p] = pk_fma(wv, f2{h3, h3}, zd[p]);
                     }
                 }
+                float* o = dz + (4 * q) * kPad + 2 * kGp * kg;
 #pragma unroll
-                for (int u = 0; u < S; u++)
-#pragma unroll
-                    for (int p = 0; p < kGp; p++) *reinterpret_cast<f2*>(obase + (S * qq + u) * kPad + 2 * p) = z[u][p];
-            };
-            if (!sliced || cn > 48) a1(std::integral_constant<int, 4>{});
-            else if (cn > 32) a1(std::integral_constant<int, 3>{});
-            else if (cn > 16) a1(std::integral_constant<int, 2>{});
-            else a1(std::integral_constant<int, 1>{});
-        }
-        __syncthreads();
-        // ---- pass A2: softmax, entropy, d loss / d logits.  Folded: FOUR THREADS PER STATE (a quarter of the actions each,
-        // quad reductions by DPP), so all four waves work -- with thread = state one wave did the 21 exp / log / divide chains
-        // of 64 states while three waited: a fifth of the passes' time.  Plain: thread = transition.
-        if (sliced && (tid >> 6) * 16 >= cn) {
-            // (this wave's sixteen states are all beyond the chunk)
-        } else if (sliced) {
-            constexpr int kQ = kPad / 4;
-            const int st = tid >> 2, part = tid & 3;
-            const bool live = st < cn;
-            float zz[kQ], lp[kQ];
-#pragma unroll
-            for (int p2 = 0; p2 < kQ / 2; p2++) {
-                f2 v = *reinterpret_cast<const f2*>(dz + st * kPad + kQ * part + 2 * p2);
-                for (int sl = 1; sl < 4; sl++) v += *reinterpret_cast<const f2*>(dz + (sl * 64 + st) * kPad + kQ * part + 2 * p2);   // slices in order
-                zz[2 * p2] = v.x; zz[2 * p2 + 1] = v.y;
-            }
-            auto quad_max = [](float v) {
-                v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));
-                return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));
-            };
-            auto quad_sum = [](float v) {
-                v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
-                return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
-            };
-            float m = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < kQ; i++) if (kQ * part + i < A) { zz[i] += b2s[kQ * part + i]; m = fmaxf(m, zz[i]); }
-            m = quad_max(m);
-            float sum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < kQ; i++) if (kQ * part + i < A) { zz[i] = expf(zz[i] - m); sum += zz[i]; }
-            sum = quad_sum(sum);
-            float Hn = 0.0f;
-#pragma unroll
-            for (int i = 0; i < kQ; i++) {
-                lp[i] = 0.0f;
-                if (kQ * part + i < A) {
-                    zz[i] = zz[i] / sum;
-                    lp[i] = logf(fminf(fmaxf(zz[i], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
-                    Hn -= zz[i] * lp[i];
+                for (int p = 0; p < kGp; p++) {
+                    *reinterpret_cast<f2*>(o + 2 * p) = za[p];
+                    *reinterpret_cast<f2*>(o + kPad + 2 * p) = zb[p];
+                    *reinterpret_cast<f2*>(o + 2 * kPad + 2 * p) = zc[p];
+                    *reinterpret_cast<f2*>(o + 3 * kPad + 2 * p) = zd[p];
                 }
             }
-            Hn = quad_sum(Hn);
-            const long long* row = sga + st * kPad + kQ * part;
-            long long rk[kQ], sg = 0;
+            __syncthreads();
+            // ---- pass A2 (thread = transition): softmax, entropy, d loss / d logits (in place over the logits)
+            if (tid < cn) {
+                const int n = c0 + tid;
+                float zz[kPad];
 #pragma unroll
-            for (int i = 0; i < kQ; i++) { rk[i] = kQ * part + i < A ? row[i] : 0; sg += rk[i]; }
-            sg += __shfl_xor(sg, 1, 64);
-            sg += __shfl_xor(sg, 2, 64);
-            const float SG = (float)((double)sg * 0x1p-40), cnt = (float)ucnt[st];
-#pragma unroll
-            for (int i = 0; i < kQ; i++)
-                zz[i] = kQ * part + i < A ? (zz[i] * SG - (float)((double)rk[i] * 0x1p-40) + cnt * (ent_coef * zz[i] * (lp[i] + Hn))) * invN : 0.0f;
-            if (live) {
-#pragma unroll
-                for (int p2 = 0; p2 < kQ / 2; p2++)
-                    *reinterpret_cast<f2*>(dz + st * kPad + kQ * part + 2 * p2) = f2{zz[2 * p2], zz[2 * p2 + 1]};
-            }
-        } else if (tid < cn) {
-            const int n = c0 + tid;
-            float zz[kPad];
-#pragma unroll
-            for (int k4 = 0; k4 < kPad / 4; k4++) {
-                const f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
-                zz[4 * k4] = v.x; zz[4 * k4 + 1] = v.y; zz[4 * k4 + 2] = v.z; zz[4 * k4 + 3] = v.w;
-            }
-            float m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < kPad; k++) if (k < A) { zz[k] += b2s[k]; m = fmaxf(m, zz[k]); }
-            float sum = 0.0f;
-#pragma unroll
-            for (int k = 0; k < kPad; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
-            float Hn = 0.0f;
-            float lp[kPad];
-#pragma unroll
-            for (int k = 0; k < kPad; k++)
-                if (k < A) {
-                    zz[k] = zz[k] / sum;
-                    lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
-                    Hn -= zz[k] * lp[k];
+                for (int k4 = 0; k4 < kPad / 4; k4++) {
+                    const f4 v = *reinterpret_cast<const f4*>(dz + tid * kPad + 4 * k4);
+                    zz[4 * k4] = v.x; zz[4 * k4 + 1] = v.y; zz[4 * k4 + 2] = v.z; zz[4 * k4 + 3] = v.w;
                 }
-            const int a_n = action[n];
-            const float Gn = Gs[n];
+                float m = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < kPad; k++)
-                zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
+                for (int k = 0; k < kPad; k++) if (k < A) { zz[k] += b2s[k]; m = fmaxf(m, zz[k]); }
+                float sum = 0.0f;
 #pragma unroll
-            for (int k4 = 0; k4 < kPad / 4; k4++)
-                *reinterpret_cast<f4*>(dz + tid * kPad + 4 * k4) = f4{zz[4 * k4], zz[4 * k4 + 1], zz[4 * k4 + 2], zz[4 * k4 + 3]};
-        }
-        __syncthreads();
-        // ---- pass B: fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j] for j in {ja, jb}
-        for (int i = half; i < cn; i += 2) {
-            const float x = xa[c0 + i];
-            const float pa = __fmaf_rn(w1a, x, b1a), pb = __fmaf_rn(w1b, x, b1b);
-            const float ha = fmaxf(pa, 0.0f), hb = fmaxf(pb, 0.0f);
-            f2 d[kPad / 2];
+                for (int k = 0; k < kPad; k++) if (k < A) { zz[k] = expf(zz[k] - m); sum += zz[k]; }
+                float Hn = 0.0f;
+                float lp[kPad];
 #pragma unroll
-            for (int k4 = 0; k4 < kPad / 4; k4++) {
-                const f4 v = *reinterpret_cast<const f4*>(dz + i * kPad + 4 * k4);
-                d[2 * k4] = f2{v.x, v.y}; d[2 * k4 + 1] = f2{v.z, v.w};
+                for (int k = 0; k < kPad; k++)
+                    if (k < A) {
+                        zz[k] = zz[k] / sum;
+                        lp[k] = logf(fminf(fmaxf(zz[k], 1.1920929e-07f), 1.0f - 1.1920929e-07f));
+                        Hn -= zz[k] * lp[k];
+                    }
+                const int a_n = action[n];
+                const float Gn = Gs[n];
+#pragma unroll
+                for (int k = 0; k < kPad; k++)
+                    zz[k] = k < A ? (Gn * (zz[k] - (k == a_n ? 1.0f : 0.0f)) + ent_coef * zz[k] * (lp[k] + Hn)) * invN : 0.0f;
+#pragma unroll
+                for (int k4 = 0; k4 < kPad / 4; k4++)
+                    *reinterpret_cast<f4*>(dz + tid * kPad + 4 * k4) = f4{zz[4 * k4], zz[4 * k4 + 1], zz[4 * k4 + 2], zz[4 * k4 + 3]};
             }
-            f2 da = f2{0.0f, 0.0f}, db = f2{0.0f, 0.0f};
+            __syncthreads();
+            // ---- pass B: fc_pi.weight[:, j], fc1.weight[j], fc1.bias[j] for j in {ja, jb}
+            for (int i = half; i < cn; i += 2) {
+                const float x = xa[c0 + i];
+                const float pa = __fmaf_rn(w1a, x, b1a), pb = __fmaf_rn(w1b, x, b1b);
+                const float ha = fmaxf(pa, 0.0f), hb = fmaxf(pb, 0.0f);
+                f2 d[kPad / 2];
+#pragma unroll
+                for (int k4 = 0; k4 < kPad / 4; k4++) {
+                    const f4 v = *reinterpret_cast<const f4*>(dz + i * kPad + 4 * k4);
+                    d[2 * k4] = f2{v.x, v.y}; d[2 * k4 + 1] = f2{v.z, v.w};
+                }
+                f2 da = f2{0.0f, 0.0f}, db = f2{0.0f, 0.0f};
+#pragma unroll
+                for (int p = 0; p < kPad / 2; p++) {
+                    gWa[p] = pk_fma(d[p], f2{ha, ha}, gWa[p]);
+                    gWb[p] = pk_fma(d[p], f2{hb, hb}, gWb[p]);
+                    da = pk_fma(ca[p], d[p], da);
+                    db = pk_fma(cb[p], d[p], db);
+                }
+                float dha = da.x + da.y, dhb = db.x + db.y;
+                if (AC) {
+                    const float gv = gvs[c0 + i], gvp = -gamma * gv, xp = xps[c0 + i];
+                    const float qa = __fmaf_rn(w1a, xp, b1a), qb = __fmaf_rn(w1b, xp, b1b);
+                    gwva = __fmaf_rn(gv, ha, gwva); gwva = __fmaf_rn(gvp, fmaxf(qa, 0.0f), gwva);
+                    gwvb = __fmaf_rn(gv, hb, gwvb); gwvb = __fmaf_rn(gvp, fmaxf(qb, 0.0f), gwvb);
+                    dha = __fmaf_rn(gv, wva, dha); dhb = __fmaf_rn(gv, wvb, dhb);
+                    const float ea = gvp * wva, eb = gvp * wvb;               // d loss / d h' through fc_v
+                    if (qa > 0.0f) { gw1a = __fmaf_rn(ea, xp, gw1a); gb1a += ea; }
+                    if (qb > 0.0f) { gw1b = __fmaf_rn(eb, xp, gw1b); gb1b += eb; }
+                }
+                if (pa > 0.0f) { gw1a = __fmaf_rn(dha, x, gw1a); gb1a += dha; }
+                if (pb > 0.0f) { gw1b = __fmaf_rn(dhb, x, gw1b); gb1b += dhb; }
+            }
+            {   // fc_pi.bias: thread (k = tid & 31, part = tid >> 5) sums every 8th row of column k
+                const int k = tid & 31;
+                if (k < A) for (int i = tid >> 5; i < cn; i += 8) gb2 += dz[i * kPad + k];
+            }
+            __syncthreads();
+        }
+
+        // ---- add the two transition halves (and the 8 parts of gb2) through LDS
+        if (half == 1) {
+            float* o = comb + ja * kRow;
 #pragma unroll
             for (int p = 0; p < kPad / 2; p++) {
-                gWa[p] = pk_fma(d[p], f2{ha, ha}, gWa[p]);
-                gWb[p] = pk_fma(d[p], f2{hb, hb}, gWb[p]);
-                da = pk_fma(ca[p], d[p], da);
-                db = pk_fma(cb[p], d[p], db);
+                *reinterpret_cast<f2*>(o + 2 * p) = gWa[p];
+                *reinterpret_cast<f2*>(o + kPad + 2 * p) = gWb[p];
             }
-            float dha = da.x + da.y, dhb = db.x + db.y;
-            if (AC) {
-                const float gv = gvs[c0 + i], gvp = -gamma * gv, xp = xps[c0 + i];
-                const float qa = __fmaf_rn(w1a, xp, b1a), qb = __fmaf_rn(w1b, xp, b1b);
-                gwva = __fmaf_rn(gv, ha, gwva); gwva = __fmaf_rn(gvp, fmaxf(qa, 0.0f), gwva);
-                gwvb = __fmaf_rn(gv, hb, gwvb); gwvb = __fmaf_rn(gvp, fmaxf(qb, 0.0f), gwvb);
-                dha = __fmaf_rn(gv, wva, dha); dhb = __fmaf_rn(gv, wvb, dhb);
-                const float ea = gvp * wva, eb = gvp * wvb;               // d loss / d h' through fc_v
-                if (qa > 0.0f) { gw1a = __fmaf_rn(ea, xp, gw1a); gb1a += ea; }
-                if (qb > 0.0f) { gw1b = __fmaf_rn(eb, xp, gw1b); gb1b += eb; }
-            }
-            if (pa > 0.0f) { gw1a = __fmaf_rn(dha, x, gw1a); gb1a += dha; }
-            if (pb > 0.0f) { gw1b = __fmaf_rn(dhb, x, gw1b); gb1b += dhb; }
+            o[2 * kPad] = gw1a; o[2 * kPad + 1] = gb1a; o[2 * kPad + 2] = gw1b; o[2 * kPad + 3] = gb1b;
+            o[2 * kPad + 4] = gwva; o[2 * kPad + 5] = gwvb;
         }
-        {   // fc_pi.bias: thread (k = tid & 31, part = tid >> 5) sums every 8th row of column k
-            const int k = tid & 31;
-            if (k < A) for (int i = tid >> 5; i < cn; i += 8) gb2 += dz[i * kPad + k];
-        }
+        float* gb2s = comb + 128 * kRow;                        // [8][32]
+        gb2s[tid] = gb2;
         __syncthreads();
-    }
-
-    // ---- add the two transition halves (and the 8 parts of gb2) through LDS
-    float* comb = reinterpret_cast<float*>(smem_nn);        // [128][kPad * 2 + 4], over W2t / dz (no longer needed)
-    constexpr int kRow = kPad * 2 + 6;
-    if (half == 1) {
-        float* o = comb + ja * kRow;
+        if (half == 0) {
+            const float* o = comb + ja * kRow;
 #pragma unroll
-        for (int p = 0; p < kPad / 2; p++) {
-            *reinterpret_cast<f2*>(o + 2 * p) = gWa[p];
-            *reinterpret_cast<f2*>(o + kPad + 2 * p) = gWb[p];
+            for (int p = 0; p < kPad / 2; p++) {
+                gWa[p] += *reinterpret_cast<const f2*>(o + 2 * p);
+                gWb[p] += *reinterpret_cast<const f2*>(o + kPad + 2 * p);
+            }
+            gw1a += o[2 * kPad]; gb1a += o[2 * kPad + 1]; gw1b += o[2 * kPad + 2]; gb1b += o[2 * kPad + 3];
+            gwva += o[2 * kPad + 4]; gwvb += o[2 * kPad + 5];
         }
-        o[2 * kPad] = gw1a; o[2 * kPad + 1] = gb1a; o[2 * kPad + 2] = gw1b; o[2 * kPad + 3] = gb1b;
-        o[2 * kPad + 4] = gwva; o[2 * kPad + 5] = gwvb;
-    }
-    float* gb2s = comb + 128 * kRow;                        // [8][32]
-    gb2s[tid] = gb2;
-    __syncthreads();
-    if (half == 0) {
-        const float* o = comb + ja * kRow;
+        if (tid < A) {
+            gb2 = 0.0f;
+            for (int part = 0; part < 8; part++) gb2 += gb2s[part * 32 + tid];
+        }
+        // clip_grad_norm_(1.0): this thread's share (agents.py:192)
+        if (half == 0) {
+            sq = gw1a * gw1a + gb1a * gb1a + gw1b * gw1b + gb1b * gb1b + gwva * gwva + gwvb * gwvb;
 #pragma unroll
-        for (int p = 0; p < kPad / 2; p++) {
-            gWa[p] += *reinterpret_cast<const f2*>(o + 2 * p);
-            gWb[p] += *reinterpret_cast<const f2*>(o + kPad + 2 * p);
+            for (int p = 0; p < kPad / 2; p++) sq += gWa[p].x * gWa[p].x + gWa[p].y * gWa[p].y + gWb[p].x * gWb[p].x + gWb[p].y * gWb[p].y;
         }
-        gw1a += o[2 * kPad]; gb1a += o[2 * kPad + 1]; gw1b += o[2 * kPad + 2]; gb1b += o[2 * kPad + 3];
-        gwva += o[2 * kPad + 4]; gwvb += o[2 * kPad + 5];
-    }
-    if (tid < A) {
-        gb2 = 0.0f;
-        for (int part = 0; part < 8; part++) gb2 += gb2s[part * 32 + tid];
+        if (tid < A) sq += gb2 * gb2;
+        if (AC && tid == 255) sq += gbv * gbv;
+        __syncthreads();                                        // (the combine scratch has been read: the staging area overlays it)
+        if (half == 0) {
+            gl[ja] = gw1a; gl[jb] = gw1b; gl[kH + ja] = gb1a; gl[kH + jb] = gb1b;
+#pragma unroll
+            for (int p = 0; p < kPad / 2; p++) {
+                if (2 * p < A) { gl[2 * kH + (2 * p) * kH + ja] = gWa[p].x; gl[2 * kH + (2 * p) * kH + jb] = gWb[p].x; }
+                if (2 * p + 1 < A) { gl[2 * kH + (2 * p + 1) * kH + ja] = gWa[p].y; gl[2 * kH + (2 * p + 1) * kH + jb] = gWb[p].y; }
+            }
+            if (AC) { gl[Pp + ja] = gwva; gl[Pp + jb] = gwvb; }
+        }
+        if (tid < A) gl[2 * kH + A * kH + tid] = gb2;
+        if (AC && tid == 255) gl[Pp + kH] = gbv;
     }
 
     // Adam state of the first sweep iteration: requested here, so the HBM round trip overlaps the norm reduction and the
@@ -553,14 +741,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (kAdamPrefetch) load_state(tid);
 
     // clip_grad_norm_(1.0) (agents.py:192)
-    float sq = 0.0f;
-    if (half == 0) {
-        sq = gw1a * gw1a + gb1a * gb1a + gw1b * gw1b + gb1b * gb1b + gwva * gwva + gwvb * gwvb;
-#pragma unroll
-        for (int p = 0; p < kPad / 2; p++) sq += gWa[p].x * gWa[p].x + gWa[p].y * gWa[p].y + gWb[p].x * gWb[p].x + gWb[p].y * gWb[p].y;
-    }
-    if (tid < A) sq += gb2 * gb2;
-    if (AC && tid == 255) sq += gbv * gbv;
     const float norm = sqrtf(block_sum(sq, red));
     const float coef = fminf(1.0f, 1.0f / (norm + 1e-6f));
 
@@ -571,18 +751,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float t = (float)(step + 1);
     const float bc1 = 1.0f - powf(0.9f, t), bc2s = sqrtf(1.0f - powf(0.999f, t));
     const float step_size = lr / bc1;
-    float* gl = comb + 128 * kRow + 256;                    // [P] unscaled gradient (behind the combine scratch)
-    if (half == 0) {
-        gl[ja] = gw1a; gl[jb] = gw1b; gl[kH + ja] = gb1a; gl[kH + jb] = gb1b;
-#pragma unroll
-        for (int p = 0; p < kPad / 2; p++) {
-            if (2 * p < A) { gl[2 * kH + (2 * p) * kH + ja] = gWa[p].x; gl[2 * kH + (2 * p) * kH + jb] = gWb[p].x; }
-            if (2 * p + 1 < A) { gl[2 * kH + (2 * p + 1) * kH + ja] = gWa[p].y; gl[2 * kH + (2 * p + 1) * kH + jb] = gWb[p].y; }
-        }
-        if (AC) { gl[Pp + ja] = gwva; gl[Pp + jb] = gwvb; }
-    }
-    if (tid < A) gl[2 * kH + A * kH + tid] = gb2;
-    if (AC && tid == 255) gl[Pp + kH] = gbv;
     __syncthreads();
     for (int i0 = tid; i0 < P; i0 += 256 * kB) {
         float gg[kB];
@@ -685,7 +853,7 @@ size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
     const size_t work = sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
-                            (value_head ? 2 * nx + kH : nx / 2 + kHash + kUmax + 8 + kHash + kHash / 2 + 2 * (size_t)kUmax * pad));
+                            (value_head ? 2 * nx + kH : nx / 2 + kXu + kUmax + 8 + 2 * (size_t)kUmax * pad));
     // the Adam sweep stages the gradient [P] behind the combine scratch [128][2 pad + 6] + [256]
     const size_t stage = sizeof(float) * (128 * (2 * pad + 6) + 256 + (size_t)(2 * kH + A * kH + A + (value_head ? kH + 1 : 0)));
     return work > stage ? work : stage;
