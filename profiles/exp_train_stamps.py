@@ -27,10 +27,10 @@ for rb in mb.nn.values():
     wrap(rb)
 mb.run(1, per_game_logs=False)
 torch.cuda.synchronize()
-raw = stamps["g"].cpu().numpy().reshape(-1).view(np.uint64)[:G * 16].reshape(G, 16)      # the kernel writes 16 u64 per block from the buffer's start
-d = np.diff(raw[:, :8].astype(np.int64), axis=1)                            # cycles between stamps (100 MHz? no: shader clock)
-names = ["loads", "recurrence", "z-score", "dedupe", "passes", "combine+norm", "adam"]
-tot = (raw[:, 7] - raw[:, 0]).astype(np.float64)
-print(which, "median cycles per block:", np.median(tot), "= %.1f us at 2.37 GHz" % (np.median(tot) / 2370))
+raw = stamps["g"].cpu().numpy().reshape(-1).view(np.uint64)[:G * 16].reshape(G, 16).astype(np.float64)   # 16 accumulated phase times per block
+names = ["loads + z-score", "hash insert", "rank / sort", "thresholds", "chunk: zero", "chunk: scatter + returns", "chunk: prefix A/B",
+         "chunk: softmax", "chunk: prefix d", "chunk: gather", "finish gradient", "adam prefetch", "norm + adam sweep"]
+tot = raw[:, :13].sum(axis=1)
+print(which, "median cycles per block (s_memtime ticks, 100 MHz):", np.median(tot), "= %.1f us" % (np.median(tot) / 100.0))
 for i, n in enumerate(names):
-    print("  %-14s median %8.0f cycles  %5.1f %%" % (n, np.median(d[:, i]), 100 * np.median(d[:, i]) / np.median(tot)))
+    print("  %-26s median %8.0f ticks  %5.1f %%" % (n, np.median(raw[:, i]), 100 * np.median(raw[:, i]) / np.median(tot)))

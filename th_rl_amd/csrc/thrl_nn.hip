@@ -73,6 +73,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// round(v * 2^40) as int64 for |v| < 2^22: two 32-bit conversions of the rounded product instead of the library's emulated
+// double -> int64 (a dozen of these per thread and chunk in the folded update)
+__device__ __forceinline__ long long fix40(double v) {
+    const double xr = rint(v * 1099511627776.0);                        // integer valued
+    const double hi = floor(xr * 0x1p-32);
+    const unsigned lo = (unsigned)__builtin_fma(-hi, 4294967296.0, xr);   // in [0, 2^32), exact
+    return (long long)(((unsigned long long)(unsigned)(int)hi << 32) | (unsigned long long)lo);
+}
+
 __device__ __forceinline__ int train_xs_len(int N) { return (N + kChunk - 1) / kChunk * kChunk; }
 
 // AC = true: ActorCritic.train_net (agents.py:280-305) as the reference executes it -- `rewards` [N]
@@ -269,44 +278,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     di[r] = before[r] + __popcll(occ[r] & lt);
                     if (key[r] != kEmpty) dense[di[r]] = key[r];
                 }
-                if (U <= 96) {
-                    // few states (two policies on one grid: 41): thread i < U counts the keys below packed key i -- two waves at most
+                {
+                    // rank of packed key i = the number of keys below it: thread i (and i + 256) counts over the U keys, every read a
+                    // broadcast, eight in flight.  (A bitonic sort in LDS was three times slower at 441 keys: 45 dependent
+                    // LDS round trips; with 41 keys only the first wave has work.)
                     __syncthreads();
+                    const bool two = tid + 256 < U;
+                    const unsigned mine0 = tid < U ? dense[tid] : 0u, mine1 = two ? dense[tid + 256] : 0u;
+                    int rank0 = 0, rank1 = 0;
                     if (tid < U) {
-                        const unsigned mine = dense[tid];
-                        int rank = 0;
-                        for (int j = 0; j < U; j++) rank += dense[j] < mine ? 1 : 0;
-                        rankd[tid] = (unsigned short)rank;
-                        xu[rank] = __uint_as_float(mine);
+                        int j2 = 0;
+                        for (; j2 + 8 <= U; j2 += 8) {
+                            unsigned kj[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) kj[u] = dense[j2 + u];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) { rank0 += kj[u] < mine0 ? 1 : 0; rank1 += kj[u] < mine1 ? 1 : 0; }
+                        }
+                        for (; j2 < U; j2++) { const unsigned kj = dense[j2]; rank0 += kj < mine0 ? 1 : 0; rank1 += kj < mine1 ? 1 : 0; }
+                        rankd[tid] = (unsigned short)rank0;
+                        xu[rank0] = __uint_as_float(mine0);
+                        if (two) { rankd[tid + 256] = (unsigned short)rank1; xu[rank1] = __uint_as_float(mine1); }
                     }
                     __syncthreads();
 #pragma unroll
                     for (int r = 0; r < kParts; r++)
                         if (key[r] != kEmpty) hrank[tid + 256 * r] = rankd[di[r]];
-                } else {
-                    // many states (a QTable opponent: up to 441 prices): bitonic sort of the packed keys, ranks by binary search
-                    int n2 = 128;
-                    while (n2 < U) n2 <<= 1;                               // <= 512 = 2 x 256 threads
-                    for (int k = U + tid; k < n2; k += 256) dense[k] = kEmpty;
-                    __syncthreads();
-                    for (int k = 2; k <= n2; k <<= 1)
-                        for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
-                            if (tid < (n2 >> 1)) {
-                                const int lo_i = ((tid & ~(j2 - 1)) << 1) | (tid & (j2 - 1)), hi_i = lo_i | j2;
-                                const unsigned a = dense[lo_i], b = dense[hi_i];
-                                const bool up = (lo_i & k) == 0;
-                                if ((a > b) == up) { dense[lo_i] = b; dense[hi_i] = a; }
-                            }
-                            __syncthreads();
-                        }
-                    for (int k = tid; k < U; k += 256) xu[k] = __uint_as_float(dense[k]);
-#pragma unroll
-                    for (int r = 0; r < kParts; r++)
-                        if (key[r] != kEmpty) {
-                            int lo = 0, hi = U;                            // first index with dense[i] >= key (it is there)
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (dense[mid] < key[r]) lo = mid + 1; else hi = mid; }
-                            hrank[tid + 256 * r] = (unsigned short)lo;
-                        }
                 }
                 __syncthreads();
 #pragma unroll
@@ -366,12 +363,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         long long* EB = EA + kUmax * kPad;                  // [kUmax][kPad]  ... B ... d * x
         static_assert(kChunk * kPad * sizeof(float) == 2 * kUmax * kPad * sizeof(long long), "EA / EB overlay dz exactly");
         const float w1 = w1s[tid], b1 = b1s[tid];           // this thread's hidden unit: j = tid
-        float wr[kPad];
-#pragma unroll
-        for (int p = 0; p < kPad / 2; p++) {
-            const f2 v = *reinterpret_cast<const f2*>(W2t + tid * kPad + 2 * p);
-            wr[2 * p] = v.x; wr[2 * p + 1] = v.y;
-        }
+        const float* wr = W2t + tid * kPad;                 // this unit's row of fc_pi^T (stays in LDS: the staging area starts behind it)
         const bool pos = !(w1 < 0.0f);                      // active states: [t, U) if pos, [0, t) otherwise
         int t;
         {
@@ -385,7 +377,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         constexpr int kBaseParts = 256 / kPad;
         int* in_base = reinterpret_cast<int*>(xs);          // [kH] (the per-transition states are no longer needed: uid has their index)
-        in_base[tid] = (pos && t == 0) || (!pos && t > 0);  // (read after the chunk loop's first barrier)
+        in_base[tid] = (pos && t == 0) || (!pos && t > 0);
+        // The units that are active from the first state on (suffix units below the range, every prefix unit that is active at
+        // all) start the running sums: about half of all units, so they are summed by (action, part) threads -- in a fixed
+        // order in float64: deterministic, one conversion -- instead of 256 x 2A atomics on the same 2A words.  (Done here,
+        // before the per-unit accumulators exist: the thirteen-wide load batches need the registers.)
+        long long base_a = 0, base_b = 0;
+        __syncthreads();
+        if (tid < kBaseParts * kPad) {
+            const int k = tid % kPad, part = tid / kPad;
+            double sa = 0.0, sb = 0.0;
+            if (k < A) {
+                constexpr int kIt = (kH + kBaseParts - 1) / kBaseParts;
+#pragma unroll
+                for (int i0 = 0; i0 < kIt; i0 += 13) {              // thirteen units' operands in flight per round trip
+                    float wv[13], w1v[13], b1v[13];
+#pragma unroll
+                    for (int u = 0; u < 13; u++) {
+                        const int j = min(part + (i0 + u) * kBaseParts, kH - 1);
+                        const bool on = i0 + u < kIt && part + (i0 + u) * kBaseParts < kH && in_base[j] != 0;
+                        wv[u] = on ? W2t[j * kPad + k] : 0.0f; w1v[u] = w1s[j]; b1v[u] = b1s[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 13; u++) { sa = fma((double)wv[u], (double)w1v[u], sa); sb = fma((double)wv[u], (double)b1v[u], sb); }
+                }
+            }
+            base_a = fix40(sa); base_b = fix40(sb);
+        }
         long long S0[kPad], S1[kPad];
 #pragma unroll
         for (int k = 0; k < kPad; k++) { S0[k] = 0; S1[k] = 0; }
@@ -399,6 +417,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
             return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
         };
+        // this thread's transitions: state index, action, return in fixed point (read once, used by every chunk)
+        constexpr int kOwnT = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
+        int t_uid[kOwnT], t_act[kOwnT];
+        long long t_ret[kOwnT];
+#pragma unroll
+        for (int q2 = 0; q2 < kOwnT; q2++) {
+            const int n = tid + 256 * q2;
+            t_uid[q2] = n < N ? (int)uid[n] : -1;
+            t_act[q2] = n < N ? action[n] : 0;
+            t_ret[q2] = n < N ? fix40((double)Gs[n]) : 0;
+        }
         for (int c0 = 0; c0 < U; c0 += kUmax) {
             const int cn = min(kUmax, U - c0);
             for (int k = tid; k < 2 * kUmax * kPad; k += 256) EA[k] = 0;
@@ -415,49 +444,54 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                     for (int k = 0; k < kPad; k++)
                         if (k < A) {
-                            const long long ia = llrint((double)wr[k] * (double)w1v * kFix), ib = llrint((double)wr[k] * (double)b1v * kFix);
+                            const long long ia = fix40((double)wr[k] * (double)w1v), ib = fix40((double)wr[k] * (double)b1v);
                             atomicAdd(reinterpret_cast<u64*>(&EA[rel * kPad + k]), (u64)(pos ? ia : -ia));
                             atomicAdd(reinterpret_cast<u64*>(&EB[rel * kPad + k]), (u64)(pos ? ib : -ib));
                         }
                 }
             }
-            if (c0 == 0 && tid < kBaseParts * kPad) {
-                // the units that are active from the first state on (suffix units below the range, every prefix unit that is active
-                // at all) start the running sums: about half of all units, so they are summed by (action, part) threads instead
-                // of 256 x 2A atomics on the same 2A words
-                const int k = tid % kPad, part = tid / kPad;
-                long long sa = 0, sb = 0;
-                if (k < A)
-                    for (int j = part; j < kH; j += kBaseParts)
-                        if (in_base[j]) {
-                            const double wv = (double)W2t[j * kPad + k];
-                            sa += llrint(wv * (double)w1s[j] * kFix); sb += llrint(wv * (double)b1s[j] * kFix);
-                        }
-                atomicAdd(reinterpret_cast<u64*>(&EA[k]), (u64)sa);
-                atomicAdd(reinterpret_cast<u64*>(&EB[k]), (u64)sb);
+            if (c0 == 0 && tid < kBaseParts * kPad) {           // the units active from the first state on (summed above)
+                atomicAdd(reinterpret_cast<u64*>(&EA[tid % kPad]), (u64)base_a);
+                atomicAdd(reinterpret_cast<u64*>(&EB[tid % kPad]), (u64)base_b);
             }
             // returns of this chunk's states by (state, action), and their transition counts
-            for (int n = tid; n < N; n += 256) {
-                const int u = (int)uid[n] - c0;
-                if (u >= 0 && u < cn) {
-                    atomicAdd(reinterpret_cast<u64*>(&sga[u * kPad + action[n]]), (u64)llrint((double)Gs[n] * kFix));
+#pragma unroll
+            for (int q2 = 0; q2 < kOwnT; q2++) {
+                const int u = t_uid[q2] - c0;
+                if (t_uid[q2] >= 0 && u >= 0 && u < cn) {
+                    atomicAdd(reinterpret_cast<u64*>(&sga[u * kPad + t_act[q2]]), (u64)t_ret[q2]);
                     atomicAdd(&ucnt[u], 1);
                 }
             }
             __syncthreads();
-            if (tid < 2 * kPad) {                           // running sums over the sorted states: A_k(s), B_k(s) in place
-                long long* arr = (tid < kPad ? EA : EB) + (tid < kPad ? tid : tid - kPad);
-                for (int s0 = 0; s0 < kUmax; s0 += 16) {
+            // running sums over the sorted states, A_k(s) and B_k(s) in place: FOUR threads per column, a quarter of the states
+            // each (one batch of 16 loads in flight instead of four in sequence), quarter totals exchanged inside the quad
+            auto column_prefix = [&](long long carry_in, long long& carry_out) {
+                const int col = tid >> 2, qtr = tid & 3;            // col < 2 kPad: EA columns, then EB columns
+                if (col < 2 * kPad) {
+                    long long* arr = (col < kPad ? EA : EB) + (col < kPad ? col : col - kPad) + qtr * 16 * kPad;
                     long long v[16];
 #pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = arr[(s0 + u) * kPad];
+                    for (int u = 0; u < 16; u++) v[u] = arr[u * kPad];
 #pragma unroll
-                    for (int u = 0; u < 16; u++) { run += v[u]; arr[(s0 + u) * kPad] = run; }
+                    for (int u = 1; u < 16; u++) v[u] += v[u - 1];
+                    const long long tot = v[15];
+                    const long long t1 = __shfl_up(tot, 1, 4), t2 = __shfl_up(tot, 2, 4), t3 = __shfl_up(tot, 3, 4);
+                    const long long off = carry_in + (qtr > 0 ? t1 : 0) + (qtr > 1 ? t2 : 0) + (qtr > 2 ? t3 : 0);
+#pragma unroll
+                    for (int u = 0; u < 16; u++) arr[u * kPad] = v[u] + off;
+                    carry_out = __shfl(v[15] + off, 3, 4);          // the column's last value, in all four threads
                 }
-            }
+            };
+            column_prefix(run, run);
             __syncthreads();
             // softmax, entropy, d loss / d logits folded over the transitions of each state: four threads per state
-            if ((tid >> 6) * 16 < cn) {
+            if ((tid >> 6) * 16 >= cn) {
+                // (this wave's sixteen states are all beyond the chunk: their rows enter the prefix as zeros)
+                const int st = tid >> 2, part = tid & 3;
+#pragma unroll
+                for (int i = 0; i < kQ; i++) { EA[st * kPad + kQ * part + i] = 0; EB[st * kPad + kQ * part + i] = 0; }
+            } else {
                 const int st = tid >> 2, part = tid & 3;
                 const bool live = st < cn;
                 const double x = (double)xu[c0 + st];
@@ -499,22 +533,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int i = 0; i < kQ; i++) {
                     const int k = kQ * part + i;
                     const float d = (k < A && live) ? (zz[i] * SG - (float)((double)rk[i] * kUnfix) + cnt * (ent_coef * zz[i] * (lp[i] + Hn))) * invN : 0.0f;
-                    EA[st * kPad + k] = llrint((double)d * kFix);
-                    EB[st * kPad + k] = llrint((double)d * x * kFix);
+                    EA[st * kPad + k] = fix40((double)d);
+                    EB[st * kPad + k] = fix40((double)d * x);
                 }
             }
             __syncthreads();
-            if (tid < 2 * kPad) {                           // inclusive prefix of d_s[k] (EA) and d_s[k] * x_s (EB) over the chunk
-                long long* arr = (tid < kPad ? EA : EB) + (tid < kPad ? tid : tid - kPad);
-                long long acc = 0;
-                for (int s0 = 0; s0 < cn; s0 += 16) {       // (rows >= cn of the last 16 are stale: never read)
-                    long long v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) v[u] = arr[(s0 + u) * kPad];
-#pragma unroll
-                    for (int u = 0; u < 16; u++) { acc += v[u]; arr[(s0 + u) * kPad] = acc; }
-                }
-                if (tid < kPad) gb2i += arr[(cn - 1) * kPad];
+            {   // inclusive prefix of d_s[k] (EA) and d_s[k] * x_s (EB) over the chunk (rows >= cn hold zeros)
+                long long last = 0;
+                column_prefix(0, last);
+                if ((tid & 3) == 0 && (tid >> 2) < kPad) gb2i += last;      // sum of d_s[k] over the chunk: d b2
             }
             __syncthreads();
             {   // this unit's range sums over the chunk
@@ -548,9 +575,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float gw1 = (float)dw1, gb1 = (float)db1;
         gl[tid] = gw1; gl[kH + tid] = gb1;
         sq += gw1 * gw1 + gb1 * gb1;
-        if (tid < A) {
+        if ((tid & 3) == 0 && (tid >> 2) < A) {
             const float gb2 = (float)((double)gb2i * kUnfix);
-            gl[2 * kH + A * kH + tid] = gb2;
+            gl[2 * kH + A * kH + (tid >> 2)] = gb2;
             sq += gb2 * gb2;
         }
     } else {
