@@ -95,6 +95,75 @@ def test_train_many_games_vs_oracle_and_init():
         assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4
 
 
+def _gradients_float64(w, A, price, action, G, entropy_coef):
+    """nn_oracle.gradients (agents.py:183-192) evaluated in float64 from the float32 weights, prices and z-scored returns."""
+    w1, b1, W2, b2 = [np.asarray(v, np.float64) for v in NN.split(w, A)]
+    x = np.asarray(price, np.float64).astype(np.float32).astype(np.float64)[:, None]
+    pre32 = (x.astype(np.float32) * NN.split(w, A)[0][None, :] + NN.split(w, A)[1][None, :])      # the activation test is float32's
+    pre = x * w1[None, :] + b1[None, :]
+    h = np.where(pre32 > 0, pre, 0.0)
+    z = h @ W2.T + b2[None, :]
+    z = z - z.max(axis=1, keepdims=True)
+    p = np.exp(z); p = p / p.sum(axis=1, keepdims=True)
+    n = len(p)
+    onehot = np.zeros((n, A)); onehot[np.arange(n), np.asarray(action, np.int64)] = 1
+    eps = np.finfo(np.float32).eps
+    logp = np.log(np.clip(p, eps, 1 - eps))
+    Hn = -(p * logp).sum(axis=1, keepdims=True)
+    dz = (np.asarray(G, np.float64)[:, None] * (p - onehot) + entropy_coef * p * (logp + Hn)) / n
+    dh = (dz @ W2) * (pre32 > 0)
+    g = np.concatenate([(dh * x).sum(axis=0), dh.sum(axis=0), (dz.T @ h).ravel(), dz.sum(axis=0)])
+    return g * min(1.0, 1.0 / (np.sqrt((g ** 2).sum()) + 1e-6))
+
+
+@pytest.mark.parametrize("A,states", [(21, 41), (21, 400), (21, 448), (21, 0), (30, 41), (30, 300), (30, 0), (5, 130), (8, 64), (24, 65)])
+def test_train_net_every_update_path_vs_oracle(A, states):
+    """The update kernel's paths against the numpy restatement of Reinforce.train_net (agents.py:170-194), per game:
+    folded on the piecewise-linear form with 1 / 2 / 7 chunks of distinct states (states = how many distinct prices the batch
+    visits), the plain per-transition path (states = 0: continuous prices, more distinct states than the fold takes), both
+    row paddings (A <= 24, A <= 32); units with w1 = 0 and thresholds on / beyond the visited prices are planted in game 0."""
+    from th_rl_amd.nn import ReinforceBatch
+    G, n = 5, 1000
+    rb = ReinforceBatch(G, actions=A, gamma=0.93, entropy=0.004, seed=11).init()
+    w = rb.params.cpu().numpy().copy()
+    w[0, 0:4] = 0.0                                  # fc1.weight = 0: unit active everywhere or nowhere (by its bias)
+    w[0, 256:260] = [0.5, -0.5, 0.0, 1e-3]
+    w[0, 4:8] = [1.0, -1.0, 2.0, -2.0]               # thresholds exactly on visited prices, below and above the range
+    w[0, 260:264] = [-3.0, 3.0, -1.0, 14.0]
+    rb.set_params(w)
+    w0 = rb.params.cpu().numpy().copy()
+    rs = np.random.RandomState(100 + A + states)
+    if states:
+        grid = np.sort(rs.choice(np.arange(500, 6500), states, replace=False)) / 1000.0
+        grid[:2] = [0.5, 3.0]                       # (0.5 * 2 - 1 = 0, 3 * (-1) + 3 = 0: pre-activations of exactly zero)
+        price = grid[rs.randint(0, states, (n, G))]
+        price[:states, :] = grid[:, None]           # every state is visited
+    else:
+        price = rs.uniform(0.5, 6.5, (n, G))
+    action = rs.randint(0, A, (n, G))
+    reward = rs.uniform(5, 15, (n, G))
+    g = rb.train(price, action, reward, want_grad=True).cpu().numpy()
+    w1 = rb.params.cpu().numpy()
+    for k in range(G):
+        ow, om, ov, os_, og = NN.train_net(w0[k], np.zeros(rb.P, np.float32), np.zeros(rb.P, np.float32), 0, A,
+                                           price[:, k], action[:, k], reward[:, k], 0.93, 0.004)
+        # the float32 restatement carries its own summation error (1,000-term float32 sums): 4e-6 absolute on a unit-norm gradient
+        np.testing.assert_allclose(g[k], og, rtol=2e-4, atol=4e-6, err_msg="game %d" % k)
+        # ... so the same formula in float64 is the sharper check for the folded path, whose sums are exact.  One float32
+        # rounding is free: the mean the returns are z-scored with (~140 here, so one ulp moves every return by ~1e-6 sd, agents.py:182).
+        # It shifts the gradient along a known direction (d g / d shift, by a difference quotient); the shift is fitted and
+        # bounded, the rest must agree tightly.
+        Gz = NN.discounted_returns(reward[:, k], 0.93).astype(np.float64)
+        g64 = _gradients_float64(w0[k], A, price[:, k], action[:, k], Gz, 0.004)
+        if states:
+            direction = (_gradients_float64(w0[k], A, price[:, k], action[:, k], Gz + 1e-4, 0.004) - g64) / 1e-4
+            shift = float(direction @ (g[k] - g64) / (direction @ direction))
+            assert abs(shift) < 5e-6, (k, shift)
+            np.testing.assert_allclose(g[k], g64 + shift * direction, rtol=2e-5, atol=2e-7, err_msg="game %d (float64)" % k)
+        diff = np.abs(w1[k] - ow)
+        assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4, (k, float((diff > 5e-6).mean()), float(diff.max()))
+
+
 def test_nn_errors():
     from th_rl_amd._lib import ThrlError
     from th_rl_amd.nn import ReinforceBatch
