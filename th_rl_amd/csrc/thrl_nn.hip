@@ -66,9 +66,10 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
 // Rows of fc_pi^T and of dz are padded to kPad = 24 or 32 floats (zero) for aligned vector LDS reads.
 constexpr int kChunk = 256;
 constexpr int kUmax = 64;          // state folding: distinct states handled per chunk
-constexpr int kUfold = 448;        // ... and per update (beyond that: the plain per-transition path); 21 x 21 action pairs = 441 prices
+constexpr int kUfold = 1024;       // ... and per update: every transition may have its own state (env noise: continuous prices)
+constexpr int kUhash = 448;        // distinct states the hash table folds (21 x 21 action pairs = 441 prices); beyond: one state per transition
 constexpr int kHash = 1024;        // slots of the LDS table that finds them (overlaid on dz: dead before the passes start)
-constexpr int kXu = 512;           // the distinct states, zero padded to whole chunks
+constexpr int kXu = kUfold + 64;   // the distinct states, zero padded to whole chunks
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -119,8 +120,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // the hash table lives inside dz (8 KB in; the first 2 KB hold the packed keys): nothing else uses dz until the passes
     unsigned* hkeys = reinterpret_cast<unsigned*>(dz) + 2048;  // [kHash] hash table of the distinct states (float bits)
     unsigned short* hrank = reinterpret_cast<unsigned short*>(hkeys + kHash);   // [kHash] slot -> index of the state
-    static_assert((2048 + kHash) * 4 + kHash * 2 <= kChunk * 24 * 4 && kUfold <= 512, "hash table fits inside dz");
-    // (dz words 0-511: packed keys, padded to 512 for the sort; words 1024-1279: their ranks as u16)
+    static_assert((2048 + kHash) * 4 + kHash * 2 <= kChunk * 24 * 4 && kUhash <= 512 && kUfold <= 1024, "hash table fits inside dz");
+    // (dz words 0-1023: packed keys; words 1024-1279: their ranks as u16)
     const int g = blockIdx.x, tid = threadIdx.x;
     const int Pp = 2 * kH + A * kH + A;                     // policy part; fc_v follows it
     const int P = Pp + (AC ? kH + 1 : 0);
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     unsigned h = (bits * 2654435761u) >> 22;
                     int probe = 0;
                     for (; probe < kHash; probe++) {
-                        if (redi[5] > kUfold) { probe = kHash; break; }      // too many states already: plain path
+                        if (redi[5] > kUhash) { probe = kHash; break; }      // too many states already: no folding
                         const unsigned old = atomicCAS(&hkeys[h], kEmpty, bits);
                         if (old == kEmpty) atomicAdd(&redi[5], 1);
                         if (old == kEmpty || old == bits) break;
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int r = 0; r < kParts; r++) before[r] = __shfl(inc - c, 4 * r + (tid >> 6), 64);
             }
             // (the folded update costs O((states + 256) * A): it always pays)
-            U = (redi[4] != 0 || n_states > kUfold) ? 0 : n_states;
+            U = (redi[4] != 0 || n_states > kUhash) ? 0 : n_states;
             if (U > 0) {
                 // keys packed densely (in slot order), then ranked by value over the U of them
                 unsigned* dense = reinterpret_cast<unsigned*>(dz);
@@ -309,6 +310,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int q2 = 0; q2 < kOwn; q2++)
                     if ((open_mask >> q2) & 1u) uid[tid + 256 * q2] = hrank[myslot[q2]];
+            }
+            if (U == 0 && N <= kUfold) {
+                // More distinct states than the table folds (a game with env noise: continuous prices).  The piecewise-linear
+                // update does not need folding, only the order: every transition becomes its own state, ranked by (price, index).
+                __syncthreads();                            // (the hash table inside dz is dead)
+                unsigned* dense = reinterpret_cast<unsigned*>(dz);
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++)
+                    if ((open_mask >> q2) & 1u) dense[tid + 256 * q2] = __float_as_uint(xq[q2]);
+                __syncthreads();
+                int rank[kOwn];
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++) rank[q2] = 0;
+                for (int j2 = 0; j2 < N; j2 += 8) {
+                    unsigned kj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) kj[u] = dense[min(j2 + u, N - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+#pragma unroll
+                        for (int q2 = 0; q2 < kOwn; q2++) {
+                            const unsigned mine = __float_as_uint(xq[q2]);
+                            rank[q2] += (j2 + u < N && (kj[u] < mine || (kj[u] == mine && j2 + u < tid + 256 * q2))) ? 1 : 0;
+                        }
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < kOwn; q2++)
+                    if ((open_mask >> q2) & 1u) { uid[tid + 256 * q2] = (unsigned short)rank[q2]; xu[rank[q2]] = xq[q2]; }
+                U = N;
             }
         }
     } else {
