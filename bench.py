@@ -233,7 +233,7 @@ def nn_roofline(agents, env_steps, gpu_s, lib):
     return out
 
 
-def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=None):
+def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=None, noise_prob=0.0):
     """BASELINE configs[3]: neural-policy agents (agents.py:119-220) x 65,536 games through mixed.MixedGameBatch
     (fused: thrl_mixed_episodes + the batched update kernels; unfused: one launch per reference call).
     agents: rr = 2 x Reinforce, qr = the reference's shipped pairing QTable vs Reinforce, qa / qc = QTable vs
@@ -248,7 +248,7 @@ def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=
     first = dict(ag) if agents == "rr" else dict(CFG["agents"][0])
     second = {"qq": dict(CFG["agents"][1]), "qa": dict(ag, name="ActorCritic", gamma=0.98),
               "qc": {"name": "CAC", "gamma": 0.98, "states": 1, "action_range": [0.2, 0.4]}}.get(agents, dict(ag))
-    config = {"agents": [first, second], "environment": dict(CFG["environment"], noise_prob=0)}
+    config = {"agents": [first, second], "environment": dict(CFG["environment"], noise_prob=noise_prob)}   # (the shipped configs: 0)
     fused = nn_loop == "fused"
     mb = MixedGameBatch(config, n_games=G, dtype="float32", seed=0).init_tables()
     mb.run(warmup, fused=fused, per_game_logs=False) if fused else mb.run(warmup, fused=False)
@@ -270,8 +270,9 @@ def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=
            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": 1, "steps": steps,
            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-           "config": {"workload": "%s x %d games, %s loop, MFMA off" % (who, G, nn_loop),
-                      "network_updates": updates},
+           "config": {"workload": "%s x %d games, %s loop, MFMA off%s" %
+                                  (who, G, nn_loop, "" if not noise_prob else "; DIAGNOSTIC: env noise_prob %g (the shipped configs: 0)" % noise_prob),
+                      "network_updates": updates, "noise_prob": noise_prob},
            "roofline": nn_roofline(agents, env_steps, gpu_s, lib)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
@@ -283,7 +284,8 @@ def run_nn(agents, games, steps, warmup, nn_loop="fused", cpu_seconds=10.0, lib=
 def bench_nn(args):
     lib = library_info()
     G = args.games if args.games != (1 << 20) else 65536
-    out = run_nn(args.nn_agents, G, args.steps, args.warmup, args.nn_loop, 0.0 if args.no_cpu_baseline else args.cpu_seconds, lib)
+    out = run_nn(args.nn_agents, G, args.steps, args.warmup, args.nn_loop, 0.0 if args.no_cpu_baseline else args.cpu_seconds, lib,
+                 noise_prob=float(args.noise_prob or 0.0))
     out["library"] = lib
     print(json.dumps(out))
 
