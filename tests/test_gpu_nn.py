@@ -401,6 +401,34 @@ def test_actorcritic_act_and_train_match_reference(tag):
         assert int(a.cpu()[0]) == int(d[tag + "_probe_greedy2"][j])
 
 
+@pytest.mark.parametrize("A,states", [(21, 41), (21, 300), (15, 64), (21, 448), (21, 0), (24, 41), (30, 41)])
+def test_actorcritic_train_every_update_path_vs_oracle(A, states):
+    """ActorCritic.train_net (agents.py:280-305) through the update kernel's paths against the numpy restatement, per game:
+    states > 0: the folded path on the piecewise-linear form (states and next states folded together, the value head as one
+    more output column; 1 / 2 / 5 / 7 chunks); states = 0: continuous prices -> the plain per-transition path; A = 24: no free
+    column for the value head -> plain path; A = 30: the wider row padding."""
+    G, n = 4, 1000
+    ab = _ac(G, A, gamma=0.9, entropy=0.005, seed=5).init()
+    w0 = ab.params.cpu().numpy().copy()
+    rs = np.random.RandomState(300 + A + states)
+    if states:
+        grid = np.sort(rs.choice(np.arange(500, 6500), states, replace=False)) / 1000.0
+        idx = rs.randint(0, states, (n + 1, G)); idx[:states, :] = np.arange(states)[:, None]
+        price, nprice = grid[idx[:-1]], grid[idx[1:]]
+    else:
+        pr = rs.uniform(0.5, 6.5, (n + 1, G)); price, nprice = pr[:-1], pr[1:]
+    action = rs.randint(0, A, (n, G)); reward = rs.uniform(5, 15, (n, G))
+    g = ab.train(price, action, reward, want_grad=True, next_price=nprice).cpu().numpy()
+    w1 = ab.params.cpu().numpy()
+    for k in range(G):
+        ow, om, ov, os_, og = NN.ac_train_net(w0[k], np.zeros(ab.P, np.float32), np.zeros(ab.P, np.float32), 0, A,
+                                              price[:, k], action[:, k], reward[:, k], nprice[:, k], 0.9, 0.005)
+        np.testing.assert_allclose(g[k], og, rtol=5e-4, atol=4e-6, err_msg="game %d" % k)
+        diff = np.abs(w1[k] - ow)
+        assert (diff > 5e-6).mean() < 0.002 and diff.max() <= 4.1e-4, (k, float((diff > 5e-6).mean()), float(diff.max()))
+
+
+
 def test_actorcritic_many_games_vs_oracle_and_init():
     """Independent weights per game (device init: fc_v bias 1000), ragged n, 32-action policy."""
     G, n, A = 24, 613, 29

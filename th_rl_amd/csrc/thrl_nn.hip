@@ -70,6 +70,10 @@ constexpr int kUfold = 1024;       // ... and per update: every transition may h
 constexpr int kUhash = 448;        // distinct states the hash table folds (21 x 21 action pairs = 441 prices); beyond: one state per transition
 constexpr int kHash = 1024;        // slots of the LDS table that finds them (overlaid on dz: dead before the passes start)
 constexpr int kXu = kUfold + 64;   // the distinct states, zero padded to whole chunks
+constexpr int kXuAc = 512;         // ... of an ActorCritic batch (states and next states together; hash fold only)
+__host__ __device__ constexpr size_t train_ac_fold_bytes(int pad) {      // sga [kUmax][pad] i64 | vstate [kUhash] f32 | gvfix [kUhash] i64
+    return (size_t)kUmax * pad * 8 + (size_t)kUhash * 4 + (size_t)kUhash * 8;
+}
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -100,23 +104,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (gamma_g) gamma = (float)gamma_g[blockIdx.x];        // per-game sweeps (main.py:13-21 as one batch)
     if (ent_g) ent_coef = (float)ent_g[blockIdx.x];
     const int NX = train_xs_len(N);
-    float* W2t = reinterpret_cast<float*>(smem_nn);         // [kH][kPad]  fc_pi.weight transposed
+    float* W2t = reinterpret_cast<float*>(smem_nn);         // [kH][kPad]  fc_pi.weight transposed (AC: column A = fc_v.weight)
     float* dz = W2t + kH * kPad;                            // [kChunk][kPad]
-    float* xs = dz + kChunk * kPad;                         // [NX]
-    float* Gs = xs + NX;                                    // [NX]
-    float* w1s = Gs + NX;                                   // [kH]
-    float* b1s = w1s + kH;                                  // [kH]
-    float* b2s = b1s + kH;                                  // [kMaxA]
-    float* red = b2s + kMaxA;                               // [8]
-    float* xps = red + 8;                                   // [NX]  next states           (AC only)
-    float* gvs = xps + (AC ? NX : 0);                       // [NX]  c_i, then d loss/d v_i (AC only)
-    float* wvs = gvs + (AC ? NX : 0);                       // [kH]  fc_v.weight            (AC only)
-    // Reinforce only: state dedupe (see below)
-    unsigned short* uid = reinterpret_cast<unsigned short*>(red + 8);   // [NX]  index of the transition's distinct state
-    float* xu = reinterpret_cast<float*>(uid + NX);         // [kXu] the distinct states in ascending order, zero padded
-    int* ucnt = reinterpret_cast<int*>(xu + kXu);           // [kUmax] transitions per state of the current chunk
-    int* redi = ucnt + kUmax;                               // [8]
-    long long* sga = reinterpret_cast<long long*>(redi + 8);   // [kUmax][kPad] returns by (state, action) of the chunk, 2^-40 fixed point
+    // Reinforce:   xs | Gs | w1s | b1s | b2s | red | uid | xu | ucnt | redi | sga
+    // ActorCritic: w1s | b1s | xs | Gs | xps | gvs | wvs | (pad) | uid | uidp | xu | ucnt | redi | b2s | red, and the folded path's
+    //              accumulators sga | vstate | gvfix OVER w1s .. wvs (+ pad), which are dead by then (train_ac_fold_bytes)
+    float* xs; float* Gs; float* w1s; float* b1s; float* b2s; float* red; float* xps; float* gvs; float* wvs;
+    unsigned short* uid; unsigned short* uidp; float* xu; int* ucnt; int* redi; long long* sga;
+    float* vstate = nullptr;                                // [kUhash] v(x) of every distinct state            (AC fold)
+    long long* gvfix = nullptr;                             // [kUhash] d loss / d v summed per state, fixed point (AC fold)
+    if (!AC) {
+        xs = dz + kChunk * kPad; Gs = xs + NX; w1s = Gs + NX; b1s = w1s + kH; b2s = b1s + kH; red = b2s + kMaxA;
+        xps = red + 8; gvs = xps; wvs = gvs;                // (unused)
+        uid = reinterpret_cast<unsigned short*>(red + 8);   // [NX]  index of the transition's distinct state
+        uidp = uid;
+        xu = reinterpret_cast<float*>(uid + NX);            // [kXu] the distinct states in ascending order, zero padded
+        ucnt = reinterpret_cast<int*>(xu + kXu);            // [kUmax] transitions per state of the current chunk
+        redi = ucnt + kUmax;                                // [8]
+        sga = reinterpret_cast<long long*>(redi + 8);       // [kUmax][kPad] returns by (state, action) of the chunk, 2^-40 fixed point
+    } else {
+        w1s = dz + kChunk * kPad; b1s = w1s + kH;
+        xs = b1s + kH; Gs = xs + NX;
+        xps = Gs + NX;                                      // [NX]  next states
+        gvs = xps + NX;                                     // [NX]  c_i, then d loss/d v_i (plain path)
+        wvs = gvs + NX;                                     // [kH]  fc_v.weight
+        const size_t region = (size_t)(reinterpret_cast<unsigned char*>(wvs + kH) - reinterpret_cast<unsigned char*>(w1s));
+        const size_t need = train_ac_fold_bytes(kPad);
+        uid = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(w1s) + (region > need ? region : need));   // [NX] index of the transition's state ...
+        uidp = uid + NX;                                    // [NX]  ... and of its next state
+        xu = reinterpret_cast<float*>(uidp + NX);           // [kXuAc]
+        ucnt = reinterpret_cast<int*>(xu + kXuAc);
+        redi = ucnt + kUmax;
+        b2s = reinterpret_cast<float*>(redi + 8);           // (behind everything the gradient staging area overlays: the norm's
+        red = b2s + kMaxA;                                  //  reduction scratch is used while the staged gradient is live)
+        sga = reinterpret_cast<long long*>(w1s);
+        vstate = reinterpret_cast<float*>(sga + kUmax * kPad);
+        gvfix = reinterpret_cast<long long*>(vstate + kUhash);
+    }
     // the hash table lives inside dz (8 KB in; the first 2 KB hold the packed keys): nothing else uses dz until the passes
     unsigned* hkeys = reinterpret_cast<unsigned*>(dz) + 2048;  // [kHash] hash table of the distinct states (float bits)
     unsigned short* hrank = reinterpret_cast<unsigned short*>(hkeys + kHash);   // [kHash] slot -> index of the state
@@ -137,7 +161,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto stage_weights = [&](int r0, int stride) {
         for (int r = r0; r < kH; r += stride) {
             for (int k = 0; k < A; k++) W2t[r * kPad + k] = w[2 * kH + k * kH + r];
-            for (int k = A; k < kPad; k++) W2t[r * kPad + k] = 0.0f;
+            for (int k = A; k < kPad; k++) W2t[r * kPad + k] = (AC && k == A) ? w[Pp + r] : 0.0f;     // (the folded path's value column)
             w1s[r] = w[r]; b1s[r] = w[kH + r];
             if (r < kMaxA) b2s[r] = r < A ? w[2 * kH + A * kH + r] : 0.0f;
             if (AC) wvs[r] = w[Pp + r];
@@ -194,6 +218,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float sd = sqrtf(block_sum(part, red) / (float)(N - 1));      // torch.std: unbiased
         for (int n = tid; n < N; n += 256) Gs[n] = (Gs[n] - mean) / sd;
         __syncthreads();
+    }
+    {
         // ---- State dedupe.  In a noise-free game the price takes one value per pair of actions, so
         // the n transitions visit few DISTINCT states (two agents on the same grid: 41).  The forward
         // pass depends on the state only, and every gradient is linear in d loss/d logits, so the
@@ -204,17 +230,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // are accumulated in 2^-40 fixed point with integer LDS atomics: order independent, so the
         // update stays deterministic.  The states are taken kUmax at a time; more than kUfold distinct
         // states: the plain path.
+        // ActorCritic: the states AND the next states of the batch are folded together (v is needed at both).
         {
-            constexpr int kOwn = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
+            constexpr int kOwn1 = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
+            constexpr int kOwn = AC ? 2 * kOwn1 : kOwn1;        // values per thread: x of transition tid + 256 q, then x'
             float xq[kOwn];
             unsigned open_mask = 0u;
 #pragma unroll
             for (int q2 = 0; q2 < kOwn; q2++) {
-                const int n = tid + 256 * q2;
-                xq[q2] = n < N ? xs[n] : 0.0f;
+                const int n = tid + 256 * (q2 % kOwn1);
+                xq[q2] = n < N ? (q2 < kOwn1 ? xs[n] : xps[n]) : 0.0f;
                 if (n < N) open_mask |= 1u << q2;
             }
-            for (int k = tid; k < kXu; k += 256) xu[k] = 0.0f;
+            for (int k = tid; k < (AC ? kXuAc : kXu); k += 256) xu[k] = 0.0f;
             // distinct states by open addressing in a kHash-slot LDS table (key = the float32 state's
             // bits), then numbered by ascending key so the numbering -- and with it the order of
             // every later sum -- does not depend on which thread won which slot
@@ -267,7 +295,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int r = 0; r < kParts; r++) before[r] = __shfl(inc - c, 4 * r + (tid >> 6), 64);
             }
             // (the folded update costs O((states + 256) * A): it always pays)
-            U = (redi[4] != 0 || n_states > kUhash) ? 0 : n_states;
+            U = (redi[4] != 0 || n_states > kUhash || (AC && (A >= kPad || NX > 1024))) ? 0 : n_states;   // (AC: the value head takes column A; the accumulators overlay Gs beyond 1,024 transitions)
             if (U > 0) {
                 // keys packed densely (in slot order), then ranked by value over the U of them
                 unsigned* dense = reinterpret_cast<unsigned*>(dz);
@@ -309,9 +337,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 __syncthreads();
 #pragma unroll
                 for (int q2 = 0; q2 < kOwn; q2++)
-                    if ((open_mask >> q2) & 1u) uid[tid + 256 * q2] = hrank[myslot[q2]];
+                    if ((open_mask >> q2) & 1u) (q2 < kOwn1 ? uid : uidp)[tid + 256 * (q2 % kOwn1)] = hrank[myslot[q2]];
             }
-            if (U == 0 && N <= kUfold) {
+            if (!AC && U == 0 && N <= kUfold) {
                 // More distinct states than the table folds (a game with env noise: continuous prices).  The piecewise-linear
                 // update does not need folding, only the order: every transition becomes its own state, ranked by (price, index).
                 __syncthreads();                            // (the hash table inside dz is dead)
@@ -341,7 +369,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 U = N;
             }
         }
-    } else {
+    }
+    if (AC && U == 0) {
         // v(s), v(s') per transition (agents.py:287-288), c_i = gamma*v'_i - v_i
         const float bv = w[Pp + kH];
         float cpart = 0.0f, rpart = 0.0f;
@@ -374,7 +403,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int kRow = kPad * 2 + 6;
     float* gl = comb + 128 * kRow + 256;                    // [P] unscaled gradient for the Adam sweep (behind the combine scratch)
     float sq = 0.0f;                                        // this thread's share of |gradient|^2
-    if (!AC && U > 0) {
+    if (U > 0) {
         // ---- Folded update on the PIECEWISE-LINEAR form of the network.  The policy has ONE input (the price, agents.py:127-133:
         // Linear(1, 256) -> relu -> Linear(256, A)), so unit j is active on a half line of prices: with the distinct states
         // sorted (xu ascending) its active states are a suffix (w1 > 0) or a prefix (w1 < 0) starting / ending at a threshold
@@ -387,8 +416,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         //             prefix arrays over the sorted states.
         // O((U + 256) * A) operations instead of O(U * 256 * A).  All sums are integers in 2^-40 fixed point (LDS integer
         // atomics: order independent, deterministic; range sums are exact differences), combined in float64 at the end.
-        constexpr double kFix = 1099511627776.0, kUnfix = 0x1p-40;
+        // ActorCritic (agents.py:222-305): the value head fc_v is one more output column (column A of W2t), v(x) is piecewise linear
+        // in the price like the logits, and its "d loss / d logits" per state is the sum of d loss / d v_i over the transitions
+        // that start there plus d loss / d v'_i over those that end there -- the rest is the same machinery.
+        constexpr double kUnfix = 0x1p-40;
         typedef unsigned long long u64;
+        const int Acols = A + (AC ? 1 : 0);
         long long* EA = reinterpret_cast<long long*>(dz);   // [kUmax][kPad]  buckets -> A per state -> d -> prefix of d
         long long* EB = EA + kUmax * kPad;                  // [kUmax][kPad]  ... B ... d * x
         static_assert(kChunk * kPad * sizeof(float) == 2 * kUmax * kPad * sizeof(long long), "EA / EB overlay dz exactly");
@@ -417,7 +450,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (tid < kBaseParts * kPad) {
             const int k = tid % kPad, part = tid / kPad;
             double sa = 0.0, sb = 0.0;
-            if (k < A) {
+            if (k < Acols) {
                 constexpr int kIt = (kH + kBaseParts - 1) / kBaseParts;
 #pragma unroll
                 for (int i0 = 0; i0 < kIt; i0 += 13) {              // thirteen units' operands in flight per round trip
@@ -447,7 +480,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             v = v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
             return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
         };
-        // this thread's transitions: state index, action, return in fixed point (read once, used by every chunk)
+        // this thread's transitions: state index, action, return (ActorCritic: weight r + C / N) in fixed point -- read once,
+        // used by every chunk
         constexpr int kOwnT = (THRL_NN_MAX_TRANSITIONS + 255) / 256;
         int t_uid[kOwnT], t_act[kOwnT];
         long long t_ret[kOwnT];
@@ -456,8 +490,77 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int n = tid + 256 * q2;
             t_uid[q2] = n < N ? (int)uid[n] : -1;
             t_act[q2] = n < N ? action[n] : 0;
-            t_ret[q2] = n < N ? fix40((double)Gs[n]) : 0;
+            t_ret[q2] = (!AC && n < N) ? fix40((double)Gs[n]) : 0;
         }
+        if (AC) {
+            // v(x) of every distinct state first (c_i, C, R -- and with them every transition's weight -- need all of them): the
+            // running sums of the value column alone, all states at once
+            long long* EvA = reinterpret_cast<long long*>(dz);      // [512]  buckets -> A_v per state
+            long long* EvB = EvA + 512;                             // [512]
+            for (int k = tid; k < 1024; k += 256) EvA[k] = 0;
+            __syncthreads();
+            if (t > 0 && t < U) {
+                const long long ia = fix40((double)wr[A] * (double)w1), ib = fix40((double)wr[A] * (double)b1);
+                atomicAdd(reinterpret_cast<u64*>(&EvA[t]), (u64)(pos ? ia : -ia));
+                atomicAdd(reinterpret_cast<u64*>(&EvB[t]), (u64)(pos ? ib : -ib));
+            }
+            if (tid < kBaseParts * kPad && tid % kPad == A) {
+                atomicAdd(reinterpret_cast<u64*>(&EvA[0]), (u64)base_a);
+                atomicAdd(reinterpret_cast<u64*>(&EvB[0]), (u64)base_b);
+            }
+            __syncthreads();
+            if (tid < 64) {                                         // lane l: states 8 l .. 8 l + 7
+                const float bv = w[Pp + kH];
+                long long va[8], vb[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { va[u] = EvA[8 * tid + u]; vb[u] = EvB[8 * tid + u]; }
+#pragma unroll
+                for (int u = 1; u < 8; u++) { va[u] += va[u - 1]; vb[u] += vb[u - 1]; }
+                long long ia = va[7], ib = vb[7];                   // inclusive scan of the lanes' totals
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const long long oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+                    if (tid >= d) { ia += oa; ib += ob; }
+                }
+                const long long offa = ia - va[7], offb = ib - vb[7];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int sidx = 8 * tid + u;
+                    if (sidx < U)
+                        vstate[sidx] = (float)(fma((double)(va[u] + offa) * kUnfix, (double)xu[sidx], (double)(vb[u] + offb) * kUnfix) + (double)bv);
+                }
+            }
+            for (int k = tid; k < kUhash; k += 256) gvfix[k] = 0;
+            __syncthreads();
+            // c_i = gamma v'_i - v_i, C, R; weight r_j + C / N; d loss / d v_i = -(2 / N^2)(R + N c_i), d loss / d v'_i = -gamma times it
+            float c_i[kOwnT], r_i[kOwnT];
+            float cpart = 0.0f, rpart = 0.0f;
+#pragma unroll
+            for (int q2 = 0; q2 < kOwnT; q2++) {
+                const int n = tid + 256 * q2;
+                c_i[q2] = 0.0f; r_i[q2] = 0.0f;
+                if (n < N) {
+                    const float v = vstate[uid[n]], vp = vstate[uidp[n]];
+                    c_i[q2] = gamma * vp - v; r_i[q2] = Gs[n];
+                    cpart += c_i[q2]; rpart += r_i[q2];
+                }
+            }
+            const float C = block_sum(cpart, red), R = block_sum(rpart, red);
+            const float fN = (float)N;
+#pragma unroll
+            for (int q2 = 0; q2 < kOwnT; q2++) {
+                const int n = tid + 256 * q2;
+                if (n < N) {
+                    const float wt = r_i[q2] + C / fN;                                 // column sums of adv / N
+                    const float gv = -(2.0f / (fN * fN)) * (R + fN * c_i[q2]);          // - row sums of adv * 2/N^2
+                    const float gvp = -gamma * gv;
+                    t_ret[q2] = fix40((double)wt);
+                    atomicAdd(reinterpret_cast<u64*>(&gvfix[uid[n]]), (u64)fix40((double)gv));
+                    atomicAdd(reinterpret_cast<u64*>(&gvfix[uidp[n]]), (u64)fix40((double)gvp));
+                }
+            }
+        }
+        __syncthreads();                                    // (ActorCritic: the accumulators below overlay arrays read above)
         for (int c0 = 0; c0 < U; c0 += kUmax) {
             const int cn = min(kUmax, U - c0);
             for (int k = tid; k < 2 * kUmax * kPad; k += 256) EA[k] = 0;
@@ -473,7 +576,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     asm volatile("" : "+v"(w1v), "+v"(b1v));
 #pragma unroll
                     for (int k = 0; k < kPad; k++)
-                        if (k < A) {
+                        if (k < Acols) {
                             const long long ia = fix40((double)wr[k] * (double)w1v), ib = fix40((double)wr[k] * (double)b1v);
                             atomicAdd(reinterpret_cast<u64*>(&EA[rel * kPad + k]), (u64)(pos ? ia : -ia));
                             atomicAdd(reinterpret_cast<u64*>(&EB[rel * kPad + k]), (u64)(pos ? ib : -ib));
@@ -563,8 +666,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int i = 0; i < kQ; i++) {
                     const int k = kQ * part + i;
                     const float d = (k < A && live) ? (zz[i] * SG - (float)((double)rk[i] * kUnfix) + cnt * (ent_coef * zz[i] * (lp[i] + Hn))) * invN : 0.0f;
-                    EA[st * kPad + k] = fix40((double)d);
-                    EB[st * kPad + k] = fix40((double)d * x);
+                    long long d0 = fix40((double)d), d1 = fix40((double)d * x);
+                    if (AC && k == A) {                                 // the value column: d loss / d v summed over the state's transitions
+                        d0 = live ? gvfix[c0 + st] : 0;
+                        d1 = fix40((double)d0 * kUnfix * x);
+                    }
+                    EA[st * kPad + k] = d0;
+                    EB[st * kPad + k] = d1;
                 }
             }
             __syncthreads();
@@ -583,7 +691,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const long long* l1 = EB + (lo_s > 0 ? lo_s - 1 : 0) * kPad;
 #pragma unroll
                     for (int k = 0; k < kPad; k++)
-                        if (k < A) {
+                        if (k < Acols) {
                             S0[k] += h0[k] - (lo_s > 0 ? l0[k] : 0);
                             S1[k] += h1[k] - (lo_s > 0 ? l1[k] : 0);
                         }
@@ -595,19 +703,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         double dw1 = 0.0, db1 = 0.0;
 #pragma unroll
         for (int k = 0; k < kPad; k++)
-            if (k < A) {
+            if (k < Acols) {
                 const double s0 = (double)S0[k] * kUnfix, s1 = (double)S1[k] * kUnfix;
                 const float gw = (float)((double)w1 * s1 + (double)b1 * s0);
-                gl[2 * kH + k * kH + tid] = gw;
+                if (k < A) gl[2 * kH + k * kH + tid] = gw;              // fc_pi.weight[k][j]
+                else gl[Pp + tid] = gw;                                 // fc_v.weight[j]
                 sq += gw * gw;
                 dw1 += (double)wr[k] * s1; db1 += (double)wr[k] * s0;
             }
         const float gw1 = (float)dw1, gb1 = (float)db1;
         gl[tid] = gw1; gl[kH + tid] = gb1;
         sq += gw1 * gw1 + gb1 * gb1;
-        if ((tid & 3) == 0 && (tid >> 2) < A) {
+        if ((tid & 3) == 0 && (tid >> 2) < Acols) {
+            const int col = tid >> 2;
             const float gb2 = (float)((double)gb2i * kUnfix);
-            gl[2 * kH + A * kH + (tid >> 2)] = gb2;
+            if (col < A) gl[2 * kH + A * kH + col] = gb2;               // fc_pi.bias
+            else gl[Pp + kH] = gb2;                                     // fc_v.bias: sum_i (d loss / d v_i + d loss / d v'_i)
             sq += gb2 * gb2;
         }
     } else {
@@ -909,8 +1020,17 @@ int launch_nn_act(int G, int A, const float* params, int P, const double* price,
 size_t nn_train_lds_bytes(int A, int N, int value_head) {
     const size_t pad = A <= 24 ? 24 : 32;
     const size_t nx = ((size_t)N + kChunk - 1) / kChunk * kChunk;
-    const size_t work = sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
-                            (value_head ? 2 * nx + kH : nx / 2 + kXu + kUmax + 8 + 2 * (size_t)kUmax * pad));
+    size_t work;
+    if (!value_head) {
+        // W2t | dz | xs | Gs | w1s | b1s | b2s | red | uid (u16) | xu | ucnt | redi | sga (i64)
+        work = sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + 2 * nx + 2 * kH + kMaxA + 8 +
+                                nx / 2 + kXu + kUmax + 8 + 2 * (size_t)kUmax * pad);
+    } else {
+        // W2t | dz | [w1s | b1s | xs | Gs | xps | gvs | wvs, padded to the folded path's accumulators] | uid | uidp | xu | ucnt | redi | b2s | red
+        const size_t region = sizeof(float) * (3 * (size_t)kH + 4 * nx), need = train_ac_fold_bytes((int)pad);
+        work = sizeof(float) * ((size_t)kH * pad + (size_t)kChunk * pad + kMaxA + 8) + (region > need ? region : need) +
+               2 * nx * sizeof(unsigned short) + sizeof(float) * (kXuAc + kUmax + 8);
+    }
     // the Adam sweep stages the gradient [P] behind the combine scratch [128][2 pad + 6] + [256]
     const size_t stage = sizeof(float) * (128 * (2 * pad + 6) + 256 + (size_t)(2 * kH + A * kH + A + (value_head ? kH + 1 : 0)));
     return work > stage ? work : stage;
