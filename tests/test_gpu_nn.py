@@ -798,13 +798,17 @@ def test_full_size_properties_65536_games_neural(pair):
     ("reinforce_vs_actorcritic", [dict(R_AGENT, min_memory=60), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
                                                                  "action_range": [0.2, 0.4], "min_memory": 45}], 15),
 ])
-def test_policy_tuple_kernel_equals_general_kernel_and_operator_loop(label, agents, T, dtype):
-    """thrl_ptuple.hip (two-agent noise-free games with discrete policies: the state is carried as the action pair, policy
-    CDFs are looked up) against the general fused kernel (k_mixed_wave) AND the unfused operator loop, on the same seeds over
-    several network updates and two calls: per-game logs, tables, counters, state, replay rings, epsilon, network parameters
-    and Adam state all bit-identical."""
+@pytest.mark.parametrize("noise", [0.0, 0.05, 0.6])
+def test_policy_tuple_kernel_equals_general_kernel_and_operator_loop(label, agents, T, dtype, noise):
+    """thrl_ptuple.hip (two-agent games with discrete policies: the state is carried as the action pair, policy CDFs are
+    looked up; after a step with a redrawn intercept -- env noise -- the state is off the grid and the policies are evaluated
+    on its price directly) against the general fused kernel (k_mixed_wave) AND the unfused operator loop, on the same seeds
+    over several network updates and two calls: per-game logs, tables, counters, state, replay rings, epsilon, network
+    parameters and Adam state all bit-identical."""
     from th_rl_amd.mixed import MixedGameBatch
-    config = {"agents": [dict(x) for x in agents], "environment": dict(ENV, max_steps=T, noise_prob=0.0)}
+    if noise and dtype == "float64" and label not in ("q_vs_reinforce", "two_reinforce"):
+        pytest.skip("noise x float64: two pairings are enough")
+    config = {"agents": [dict(x) for x in agents], "environment": dict(ENV, max_steps=T, noise_prob=noise)}
     G, E = 7, 9
     a = MixedGameBatch(config, n_games=G, dtype=dtype, seed=33, game_offset=11).init_tables()
     b = MixedGameBatch(config, n_games=G, dtype=dtype, seed=33, game_offset=11).init_tables()
@@ -830,11 +834,11 @@ def test_policy_tuple_kernel_equals_general_kernel_and_operator_loop(label, agen
                 assert np.array_equal(a.buf[i][k][:, :n].cpu().numpy(), other.buf[i][k][:, :n].cpu().numpy()), (label, k)
 
 
-def test_policy_tuple_kernel_is_not_taken_with_noise_or_unfit_buffers():
+def test_policy_tuple_kernel_is_taken_with_noise_but_not_with_unfit_buffers():
     from th_rl_amd.mixed import MixedGameBatch
     base = [dict(Q_AGENT, min_memory=25), dict(R_AGENT, min_memory=50)]
     noisy = MixedGameBatch({"agents": [dict(x) for x in base], "environment": dict(ENV, max_steps=25, noise_prob=0.05)}, n_games=4, seed=1).init_tables()
-    assert noisy.run(2, fused=True)["episode_kernel"] == "wave"
+    assert noisy.run(2, fused=True)["episode_kernel"] == "tuple"
     spans = MixedGameBatch({"agents": [dict(Q_AGENT, min_memory=60), dict(R_AGENT, min_memory=50)],
                             "environment": dict(ENV, max_steps=25)}, n_games=4, seed=1).init_tables()     # QTable trains every 3rd episode
     assert spans.run(2, fused=True)["episode_kernel"] == "wave"

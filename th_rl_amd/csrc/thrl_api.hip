@@ -932,7 +932,6 @@ static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
 #define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
     PTupleArgs& a = p.a;
     if (c->n_agents != 2) NO("not a two-agent game");
-    if (c->noise_prob > 0.0) NO("environment noise");
     if (mx->sweep_gamma || mx->sweep_alpha || mx->sweep_eps_end || mx->sweep_eps_step || mx->sweep_eps || mx->sweep_noise_prob) NO("per-game sweeps");
     const int T = c->max_steps;
     if (T > 256) NO("more than 256 steps per episode");
@@ -972,10 +971,16 @@ static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
             while (j < npid && memcmp(&seen[j], &x, 4) != 0) j++;
             if (j == npid) seen[npid++] = x;
             if (a.qi >= 0) {
-                const int r64 = h_encode64(price, c, a.qi), r32 = h_encode32(price, c, a.qi);
-                if (r64 < 0 || r64 > c->n_states[a.qi] || r32 < 0 || r32 > c->n_states[a.qi]) NO("price outside the table on the action grid");
-                lo = r64 < lo ? r64 : lo; lo = r32 < lo ? r32 : lo;
-                hi = r64 > hi ? r64 : hi; hi = r32 > hi ? r32 : hi;
+                // (with env noise the intercept ranges over [0.7a, a]: both encodes are monotonic in the price)
+                const double intercepts[2] = {c->env_a, c->env_a * 0.7};
+                for (int v = 0; v < (c->noise_prob > 0.0 ? 2 : 1); v++) {
+                    double pr = intercepts[v] - c->env_b * Q;
+                    if (!(pr > 0.0)) pr = 0.0;
+                    const int r64 = h_encode64(pr, c, a.qi), r32 = h_encode32(pr, c, a.qi);
+                    if (r64 < 0 || r64 > c->n_states[a.qi] || r32 < 0 || r32 > c->n_states[a.qi]) NO("price outside the table on the action grid");
+                    lo = r64 < lo ? r64 : lo; lo = r32 < lo ? r32 : lo;
+                    hi = r64 > hi ? r64 : hi; hi = r32 > hi ? r32 : hi;
+                }
             }
         }
     if (npid > 2048) NO("more than 2,048 distinct prices");
@@ -1007,7 +1012,8 @@ static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
     a.aq_off = (int)align_up((size_t)a.xf_off + (size_t)npid * 4, 16);
     a.lut_lds_bytes = a.aq_off + 2 * 128 * 8;
     a.price_off = a.lut_lds_bytes;
-    if ((size_t)a.price_off + 8 * (size_t)tuples > kPTupleLutRegion - 64) NO("LUT image too large");
+    a.qsum_off = a.price_off + 8 * (int)tuples;
+    if ((size_t)a.qsum_off + 8 * (size_t)tuples > kPTupleLutRegion - 64) NO("LUT image too large");
     p.scratch_bytes = kPTupleLutRegion + (a.n_r == 1 ? (size_t)c->n_games * (size_t)(npid + 1) * apad * 4 : 0);
     const DevInfo dv = dev_info();
     const int cap_waves = a.n_r == 1 ? 12 : 16;                     // compiled for 3 / 4 waves per SIMD

@@ -127,6 +127,7 @@ struct PTupleArgs {
     int32_t qi, n_r, ri[2];         // the QTable agent (or -1), the policy agents
     int32_t waves_per_block, lut_lds_bytes, game_lds_bytes;
     int32_t qrows_off, xf_off, aq_off, price_off;        // byte offsets in the LUT image (price: HBM only)
+    int32_t qsum_off;               // total quantity per action pair [tuples] doubles (HBM only; games with env noise)
     int32_t am_off, g_off, hist_off, hist_dwords, cdf_off, logs_off;      // byte offsets in the per-game LDS region
     int32_t row_lo, win_rows;       // the QTable agent's row window
     int64_t stride;

@@ -5,7 +5,8 @@
 // bit-identical to it and to the unfused operator loop: same Philox streams, same arithmetic, per-game logs accumulated
 // in step order (rewards_log += reward / max_steps, trainer.py:65-66).
 //
-// ONE WAVEFRONT PER GAME.  Without env noise the state after a step is a function of that step's action pair
+// ONE WAVEFRONT PER GAME.  Unless the intercept was redrawn (env noise: NOISE variants, the state then carries its price and
+// the policies are evaluated on it directly) the state after a step is a function of that step's action pair
 // tau = a0 * A1 + a1, so
 //   * per block, in LDS: pid[tau] = index of tau's distinct float32 price (the policy's input, trainer.py:53), the
 //     QTable agent's window-local rows per tau, per-action quantities; the float64 price per tau stays in HBM;
@@ -33,13 +34,15 @@ using tup::Ops;
 
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ uint32_t wrlane(uint32_t old, uint32_t val, int lane) {
-    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane));
+    // (both operands are wave-uniform; readfirstlane says so to the compiler where its analysis gives up)
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0"
+        : "+v"(old) : "s"(__builtin_amdgcn_readfirstlane((int)val)), "s"(__builtin_amdgcn_readfirstlane(lane)));
     return old;
 }
 
 // T: table dtype; NR: number of policy agents (1: the other agent is a QTable; 2: none is); APAD: padded action count of the
 // CDF rows; NSEG: 64-step segments per episode; TLDS: CDF tables in LDS (else HBM scratch)
-template <typename QT, int NR, int APAD, int NSEG, bool TLDS>
+template <typename QT, int NR, int APAD, int NSEG, bool TLDS, bool NOISE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : 4)))
 k_ptuple_episodes(const PTupleArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -59,6 +62,7 @@ k_ptuple_episodes(const PTupleArgs a) {
     const double* lut_aq = reinterpret_cast<const double*>(smem + a.aq_off);                       // [2][64] (a/b) * scaled
     const double* lut_sc = lut_aq + 128;                                                           // [2][64] scaled action
     const double* price_lut = reinterpret_cast<const double*>(a.lut + a.price_off);               // [tuples] HBM / L2
+    const double* qsum_lut = reinterpret_cast<const double*>(a.lut + a.qsum_off);                 // [tuples] total quantity (NOISE)
     unsigned char* game = smem + a.lut_lds_bytes + (size_t)wib * a.game_lds_bytes;
     QT* const tab = reinterpret_cast<QT*>(game);
     unsigned char* const am = game + a.am_off;
@@ -136,6 +140,11 @@ k_ptuple_episodes(const PTupleArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         int tau = tuples;                        // `tuples` = the launch's initial (off-grid) state
+        // NOISE: a step whose intercept was redrawn (environments.py:28-31) leaves the action grid: the state after it is "off" --
+        // its price is carried, the policies are evaluated on it directly, the QTable agent reads its row by encoding it.
+        bool off = false;
+        double p_off = price0;
+        int off_qp = 0;
         double eps_q = HASQ ? a.eps0[qi] : 0.0;
         int cnt[NR];
 #pragma unroll
@@ -194,6 +203,22 @@ k_ptuple_episodes(const PTupleArgs a) {
                 for (int r = 0; r < NR; r++) UU[seg][r] = (float)u01_32((a.ri[r] & 1) ? x.z : x.x);
             }
 
+            // NOISE: the env's draw of every step, lane = step: nzm bit t = intercept redrawn, NA = its value
+            uint64_t nzm[NSEG];
+            double NA[NSEG];
+#pragma unroll
+            for (int seg = 0; seg < NSEG; seg++) {
+                nzm[seg] = 0ull; NA[seg] = a.env.a;
+                if (NOISE) {
+                    const int tt = min(seg * 64 + lane, T - 1);
+                    const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)tt, kStreamNoise);
+                    nzm[seg] = __ballot(seg * 64 + lane < T && u01_32(xn.x) < a.env.noise_prob);
+                    NA[seg] = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
+                }
+            }
+            const bool off_in = off;                                 // is the state the episode starts in off the grid, and its price
+            const double p_in = p_off;
+
             // ---- (d) play: the serial chain.  seq lane t = state step t was played in, acts lane t = a0 | a1 << 8
             uint32_t seq[NSEG], acts[NSEG];
 #pragma unroll
@@ -202,6 +227,21 @@ k_ptuple_episodes(const PTupleArgs a) {
                 const int n = min(64, T - seg * 64);
                 for (int tl = 0; tl < n; tl++) {
                     uint32_t act2[2] = {0u, 0u};
+                    if (NOISE && off) {
+                        if (HASQ) {
+                            const uint32_t gq = (uint32_t)__builtin_amdgcn_readfirstlane((int)am[off_qp]);
+                            act2[qi] = rdlane(Ex[seg], tl) ? rdlane(Ch[seg], tl) : gq;
+                        }
+                        const float x = (float)p_off;                // trainer.py:53: the policy sees the float32 state
+#pragma unroll
+                        for (int r = 0; r < NR; r++) {
+                            const int i = a.ri[r], A = a.ag[i].n_actions;
+                            if (NR == 2) policy_load(net, a.nn_params[i] + (int64_t)g * a.nn_stride[i], A, lane);   // (not resident: 5 % of the steps)
+                            const float c = policy_cdf(policy_probs(net, A, x, lane));
+                            const float uu = __builtin_bit_cast(float, rdlane(__builtin_bit_cast(uint32_t, UU[seg][r]), tl));
+                            act2[i] = (uint32_t)__builtin_amdgcn_readfirstlane(policy_pick(c, uu, A, lane));
+                        }
+                    } else {
                     if (HASQ) {
                         const uint32_t gq = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
                         act2[qi] = rdlane(Ex[seg], tl) ? rdlane(Ch[seg], tl) : gq;
@@ -235,9 +275,21 @@ k_ptuple_episodes(const PTupleArgs a) {
                         const float uu = __builtin_bit_cast(float, rdlane(__builtin_bit_cast(uint32_t, UU[seg][r]), tl));
                         act2[i] = (uint32_t)__builtin_amdgcn_readfirstlane(policy_pick(c, uu, A, lane));
                     }
+                    }
                     seq[seg] = wrlane(seq[seg], (uint32_t)tau, tl);
                     acts[seg] = wrlane(acts[seg], act2[0] | (act2[1] << 8), tl);
                     tau = (int)(act2[0] * (uint32_t)a.ag[1].n_actions + act2[1]);
+                    if (NOISE) {
+                        off = __builtin_amdgcn_readfirstlane((int)((nzm[seg] >> tl) & 1ull)) != 0;
+                        if (off) {                                   // environments.py:29-33 with the redrawn intercept
+                            const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(NA[seg]), tl),
+                                                               __builtin_amdgcn_readlane(__double2loint(NA[seg]), tl));
+                            double pr = __dsub_rn(na, __dmul_rn(a.env.b, qsum_lut[tau]));
+                            if (!(pr > 0.0)) pr = 0.0;
+                            p_off = pr;
+                            if (HASQ) off_qp = __builtin_amdgcn_readfirstlane(min(max(encode32(pr, pq) - a.row_lo, 0), a.win_rows - 1));
+                        }
+                    }
                 }
             }
             const int tau_end = tau;
@@ -246,6 +298,7 @@ k_ptuple_episodes(const PTupleArgs a) {
             uint32_t word[NSEG];
             Ops<QT> ops[NSEG];
             double acc = 0.0;                            // lane k < 4: reward of agent k (k < 2), scaled action of agent k - 2
+            double p_carry = 0.0;                        // NOISE: the price after the previous segment's last step
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 const int tt = seg * 64 + lane;
@@ -254,8 +307,22 @@ k_ptuple_episodes(const PTupleArgs a) {
                 int nxt = __shfl_down((int)seq[seg], 1, 64);
                 if (seg + 1 < NSEG) { if (lane == 63) nxt = __builtin_amdgcn_readlane((int)seq[seg + 1 < NSEG ? seg + 1 : seg], 0); }
                 if (tt + 1 >= T) nxt = tau_end;
-                const double p_next = price_lut[nxt];
-                const double p_prev = tq == tuples ? price0 : price_lut[min(tq, tuples - 1)];
+                double p_next = price_lut[nxt];
+                double p_prev = tq == tuples ? price0 : price_lut[min(tq, tuples - 1)];
+                bool s_off = false, n_off = false;                   // NOISE: my state / the state after my step is off the grid
+                if (NOISE) {
+                    n_off = valid && ((nzm[seg] >> lane) & 1ull);
+                    if (n_off) {
+                        p_next = __dsub_rn(NA[seg], __dmul_rn(a.env.b, qsum_lut[nxt]));
+                        if (!(p_next > 0.0)) p_next = 0.0;
+                    }
+                    s_off = lane > 0 ? (bool)((nzm[seg] >> (lane - 1)) & 1ull) : (seg > 0 ? (bool)((nzm[seg > 0 ? seg - 1 : 0] >> 63) & 1ull) : off_in);
+                    double pp = __shfl_up(p_next, 1, 64);
+                    if (lane == 0) pp = seg > 0 ? p_carry : p_in;
+                    p_carry = __shfl(p_next, 63, 64);
+                    if (s_off && valid) p_prev = pp;
+                    if (!valid) s_off = false;
+                }
                 double rew[2], sca[2];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
@@ -275,8 +342,12 @@ k_ptuple_episodes(const PTupleArgs a) {
                 }
                 if (HASQ) {
                     const uint32_t act = valid ? ((acts[seg] >> (8 * qi)) & 0xFFu) : 0u;
-                    const uint32_t srow = tq == tuples ? (uint32_t)init_train : (uint32_t)(qrows[min(tq, tuples - 1)] >> 8);
-                    const uint32_t ns = (uint32_t)(qrows[nxt] >> 8);
+                    uint32_t srow = tq == tuples ? (uint32_t)init_train : (uint32_t)(qrows[min(tq, tuples - 1)] >> 8);
+                    uint32_t ns = (uint32_t)(qrows[nxt] >> 8);
+                    if (NOISE) {                                     // the train rows of off-grid states: float64 encode of their price
+                        if (s_off) srow = (uint32_t)min(max(encode64(p_prev, pq) - a.row_lo, 0), a.win_rows - 1);
+                        if (n_off) ns = (uint32_t)min(max(encode64(p_next, pq) - a.row_lo, 0), a.win_rows - 1);
+                    }
                     const uint32_t cell = valid ? srow * (uint32_t)Aq + act : 0u;
                     ops[seg].set(tab[cell], rew[qi], tcq);
                     word[seg] = ns | (cell << 8);
@@ -352,12 +423,12 @@ k_ptuple_episodes(const PTupleArgs a) {
                 }
             }
         }
-        if (lane == 0 && a.n_episodes > 0) a.state[g] = price_lut[tau];
+        if (lane == 0 && a.n_episodes > 0) a.state[g] = (NOISE && off) ? p_off : price_lut[tau];
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// LUT image: pid u16 [tuples] | qrows u16 [tuples] | xf f32 [npid] | aq f64 [2][64] | sc f64 [2][64] || price f64 [tuples]
+// LUT image: pid u16 [tuples] | qrows u16 [tuples] | xf f32 [npid] | aq f64 [2][64] | sc f64 [2][64] || price f64 [tuples] | qsum f64 [tuples]
 // ONE block of 1,024 threads.  Price ids: pid[tau] = rank, in order of first occurrence, of tau's float32 price among the
 // distinct float32 prices of the grid (the host runs the same enumeration for the count: plan_ptuple).
 __global__ void __launch_bounds__(1024) k_ptuple_lut(const PTupleArgs a, unsigned char* out) {
@@ -374,6 +445,7 @@ __global__ void __launch_bounds__(1024) k_ptuple_lut(const PTupleArgs a, unsigne
         double sc[2] = {scaled(0, a0), scaled(1, a1)}, rew[2];
         const double price = env_step<2>(a.env, 2, sc, a.env.a, rew);
         reinterpret_cast<double*>(out + a.price_off)[idx] = price;
+        reinterpret_cast<double*>(out + a.qsum_off)[idx] = __dadd_rn(__dadd_rn(0.0, __dmul_rn(a.env.ratio, sc[0])), __dmul_rn(a.env.ratio, sc[1]));   // as env_step sums it
         xb[idx] = __float_as_uint((float)price);
         unsigned short qr = 0;
         if (a.qi >= 0) {
@@ -407,12 +479,12 @@ __global__ void __launch_bounds__(1024) k_ptuple_lut(const PTupleArgs a, unsigne
     }
 }
 
-template <typename QT, int NR, int APAD, bool TLDS>
+template <typename QT, int NR, int APAD, bool TLDS, bool NOISE>
 int launch_seg(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
 #define THRL_PT_LAUNCH(NS)                                                                                           \
     {                                                                                                                \
-        auto kern = k_ptuple_episodes<QT, NR, APAD, NS, TLDS>;                                                       \
+        auto kern = k_ptuple_episodes<QT, NR, APAD, NS, TLDS, NOISE>;                                                \
         if (lds > 64 * 1024) {                                                                                       \
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
@@ -427,12 +499,16 @@ int launch_seg(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t
 #undef THRL_PT_LAUNCH
 }
 
-template <typename QT>
-int launch_t(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+template <typename QT, bool NOISE>
+int launch_n(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     int amax = 0;
     for (int r = 0; r < a.n_r; r++) amax = a.ag[a.ri[r]].n_actions > amax ? a.ag[a.ri[r]].n_actions : amax;
-    if (a.n_r == 2) return amax <= 24 ? launch_seg<QT, 2, 24, true>(a, grid, block, lds, s) : launch_seg<QT, 2, 32, true>(a, grid, block, lds, s);
-    return amax <= 24 ? launch_seg<QT, 1, 24, false>(a, grid, block, lds, s) : launch_seg<QT, 1, 32, false>(a, grid, block, lds, s);
+    if (a.n_r == 2) return amax <= 24 ? launch_seg<QT, 2, 24, true, NOISE>(a, grid, block, lds, s) : launch_seg<QT, 2, 32, true, NOISE>(a, grid, block, lds, s);
+    return amax <= 24 ? launch_seg<QT, 1, 24, false, NOISE>(a, grid, block, lds, s) : launch_seg<QT, 1, 32, false, NOISE>(a, grid, block, lds, s);
+}
+template <typename QT>
+int launch_t(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    return a.env.noise_prob > 0.0 ? launch_n<QT, true>(a, grid, block, lds, s) : launch_n<QT, false>(a, grid, block, lds, s);
 }
 
 }  // namespace
