@@ -55,8 +55,13 @@ __global__ void __launch_bounds__(256) k_nn_act(int G, int A, const float* __res
     if (prob_out && !(lane & 1) && (lane >> 1) < A) prob_out[(int64_t)g * A + (lane >> 1)] = prob;
 }
 
-// train_net for one game per block (agents.py:171-193), 256 threads.
-// The n transitions are processed in chunks of kChunk = 256:
+// train_net for one game per block (agents.py:171-193; ActorCritic: agents.py:280-305), 256 threads.  Two paths:
+//   * the FOLDED path (the usual one): the policy has one input, so it is piecewise linear in the price; over the batch's
+//     sorted distinct states its forward and backward passes are running sums -- O((states + 256) A) operations, exact
+//     integer accumulation (see the comment at `if (U > 0)`).  Taken for up to 448 distinct states found by an LDS hash table
+//     (Reinforce and ActorCritic), and for Reinforce also with one state per transition (continuous prices: env noise) up to
+//     1,024 transitions;
+//   * the PLAIN path for everything else.  The n transitions are processed in chunks of kChunk = 256:
 //   pass A1  thread = (4 transitions) x (6 actions): logits.  Each fc_pi weight read from LDS
 //            feeds 4 FMAs (packed v_pk_fma_f32), so the pass is VALU-bound, not LDS-bound.
 //   pass A2  thread = transition: softmax, entropy, d loss / d logits (in place over the logits).
