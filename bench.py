@@ -287,7 +287,27 @@ def bench_nn(args):
     out = run_nn(args.nn_agents, G, args.steps, args.warmup, args.nn_loop, 0.0 if args.no_cpu_baseline else args.cpu_seconds, lib,
                  noise_prob=float(args.noise_prob or 0.0))
     out["library"] = lib
-    print(json.dumps(out))
+    emit(json.dumps(out))
+
+
+_JSON_OUT = None
+
+
+def protect_stdout():
+    """The driver reads ONE JSON line from stdout.  Libraries print there too -- gloo announces "[Gloo] Rank 0 is connected to
+    1 peer ranks" through C++ std::cout when a process group forms -- so file descriptor 1 is pointed at stderr for the rest of
+    the run and the JSON line goes to the saved, real stdout."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _JSON_OUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
 
 
 def visible_gpus():
@@ -381,6 +401,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- N child ranks, nothing touches the GPU here
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.allow_oversubscribe))
+    protect_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -574,7 +595,7 @@ def main():
             # (warm-up = the timed length: the same launch shapes, so no allocation falls into the timed region)
             out["secondary"] = [run_nn(p, 65536, 40, 40, "fused", 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 5.0), lib)
                                 for p in ("rr", "qr")]
-        print(json.dumps(out))
+        emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
