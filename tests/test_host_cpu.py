@@ -489,3 +489,17 @@ def test_policy_table_scratch_is_sized_on_the_host(lib):
     rr = need([1, 1], [r, r], [1100, 1100], [1000, 1000])
     assert rr == 64 * 1024
     assert need([0, 3], [q, dict(r, actions=2)], [200, 1100], [100, 1000]) == 0
+
+
+def test_bench_stdout_carries_only_the_json_line():
+    """bench.protect_stdout(): whatever a library writes to file descriptor 1 afterwards (gloo prints its rank banner through C++
+    std::cout) lands on stderr; emit() writes the JSON line to the real stdout -- the driver parses exactly one line."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; bench.protect_stdout(); "
+            "os.write(1, b'[Gloo] Rank 0 is connected to 1 peer ranks\\n'); print('python-level chatter'); "
+            "bench.emit(json.dumps({'metric': 'x', 'value': 1}))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == ['{"metric": "x", "value": 1}'], r.stdout
+    assert "Gloo" in r.stderr and "chatter" in r.stderr
