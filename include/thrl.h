@@ -352,8 +352,8 @@ typedef struct {
     int32_t  flags;                      /* THRL_MIXED_* */
 } thrl_mixed;
 /* Two-agent games whose neural agents are discrete run on the tuple-chain kernel (the state is carried as the action pair of
- * the last step, or as its price after a step with a redrawn intercept; needs policy_tab): same results as the general
- * kernel.  This flag keeps the general one. */
+ * the last step, or as its price after a step with a redrawn intercept; needs policy_tab; per-game sweeps are taken): same
+ * results as the general kernel.  This flag keeps the general one. */
 #define THRL_MIXED_NO_TUPLE_KERNEL 1
 /* bytes of thrl_mixed.policy_tab this configuration can use on this many games (0: the table does not apply --
  * no discrete neural agent, a continuous agent in the game, more than 2,048 action tuples, or a price grid small

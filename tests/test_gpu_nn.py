@@ -834,6 +834,44 @@ def test_policy_tuple_kernel_equals_general_kernel_and_operator_loop(label, agen
                 assert np.array_equal(a.buf[i][k][:, :n].cpu().numpy(), other.buf[i][k][:, :n].cpu().numpy()), (label, k)
 
 
+@pytest.mark.parametrize("noise", [0.0, 0.2])
+@pytest.mark.parametrize("label,agents,T", [
+    ("q_vs_reinforce", [dict(Q_AGENT, min_memory=30, capacity=64), dict(R_AGENT, min_memory=70, entropy=0.01)], 30),
+    ("reinforce_vs_q", [dict(R_AGENT, min_memory=50), dict(Q_AGENT, min_memory=25, capacity=500, actions=15)], 25),
+    ("q_vs_actorcritic_T70", [dict(Q_AGENT, min_memory=70), {"name": "ActorCritic", "gamma": 0.98, "actions": 21, "states": 1,
+                                                             "action_range": [0.2, 0.4], "min_memory": 140}], 70),
+])
+def test_policy_tuple_kernel_takes_per_game_sweeps(label, agents, T, noise):
+    """Per-game sweeps (the QTable agent's gamma / alpha / epsilon schedule, the neural agent's gamma / entropy, noise_prob) on
+    the tuple-chain kernel against the general fused kernel given the same arrays: logs, tables, counters, state, per-game
+    epsilon, rings, network parameters bit-identical over several updates and two calls."""
+    from th_rl_amd.mixed import MixedGameBatch
+    config = {"agents": [dict(x) for x in agents], "environment": dict(ENV, max_steps=T, noise_prob=noise)}
+    G, E = 9, 9
+    rs = np.random.RandomState(77)
+    sweep = dict(gamma=rs.choice([0.9, 0.95, 0.99], (2, G)), alpha=rs.choice([0.05, 0.1, 0.4], (2, G)),
+                 eps=rs.uniform(0.0, 0.8, (2, G)), eps_end=rs.choice([0.0, 0.01], (2, G)), eps_step=rs.choice([0.9, 0.999], (2, G)),
+                 entropy=rs.choice([0.0, 0.01], (2, G)))
+    if noise:
+        sweep["noise_prob"] = rs.choice([0.0, 0.1, 0.7], G)
+    a = MixedGameBatch(config, n_games=G, seed=41, sweep=sweep).init_tables()
+    b = MixedGameBatch(config, n_games=G, seed=41, sweep=sweep).init_tables()
+    b.tuple_kernel = False
+    ra1 = a.run(4, fused=True); ra2 = a.run(E - 4, fused=True)
+    rb = b.run(E, fused=True)
+    assert ra1["episode_kernel"] == "tuple" and ra2["episode_kernel"] == "tuple" and rb["episode_kernel"] == "wave", label
+    assert np.array_equal(np.concatenate([ra1["game_reward_log"], ra2["game_reward_log"]]), rb["game_reward_log"]), label
+    assert np.array_equal(a.tables_numpy(), b.tables_numpy()) and np.array_equal(a.counters_numpy(), b.counters_numpy())
+    assert np.array_equal(a.states_numpy(), b.states_numpy())
+    assert np.array_equal(a.sweep["eps"].cpu().numpy(), b.sweep["eps"].cpu().numpy())
+    for i in a.nn:
+        assert a.nn[i].step == b.nn[i].step and a.nn[i].step >= 1
+        assert np.array_equal(a.nn[i].params.cpu().numpy(), b.nn[i].params.cpu().numpy()), label
+        n = min(a.count[i], a.buf_len[i])
+        for k in ("price", "action", "reward", "nprice"):
+            assert np.array_equal(a.buf[i][k][:, :n].cpu().numpy(), b.buf[i][k][:, :n].cpu().numpy()), (label, k)
+
+
 def test_policy_tuple_kernel_is_taken_with_noise_but_not_with_unfit_buffers():
     from th_rl_amd.mixed import MixedGameBatch
     base = [dict(Q_AGENT, min_memory=25), dict(R_AGENT, min_memory=50)]

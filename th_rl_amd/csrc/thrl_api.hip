@@ -932,7 +932,6 @@ static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
 #define NO(msg) do { snprintf(p.why, sizeof(p.why), "%s", msg); return p; } while (0)
     PTupleArgs& a = p.a;
     if (c->n_agents != 2) NO("not a two-agent game");
-    if (mx->sweep_gamma || mx->sweep_alpha || mx->sweep_eps_end || mx->sweep_eps_step || mx->sweep_eps || mx->sweep_noise_prob) NO("per-game sweeps");
     const int T = c->max_steps;
     if (T > 256) NO("more than 256 steps per episode");
     a.qi = -1; a.n_r = 0;
@@ -951,6 +950,12 @@ static PTuplePlan plan_ptuple(const thrl_cfg* c, const thrl_mixed* mx) {
         } else NO("continuous agent");
     }
     if (a.n_r == 0) NO("no neural agent");
+    // per-game sweeps: the QTable agent's rows and noise_prob need the kernel's sweep variant (rows of neural agents only reach
+    // their update kernels); a game's epsilon must survive the launch in sweep_eps
+    const bool q_sweep = mx->sweep_gamma || mx->sweep_alpha || mx->sweep_eps_end || mx->sweep_eps_step || mx->sweep_eps;
+    if (a.qi < 0 && mx->sweep_noise_prob) NO("noise_prob sweep without a QTable agent in the game");
+    if (a.qi >= 0 && (mx->sweep_eps_end || mx->sweep_eps_step) && !mx->sweep_eps) NO("epsilon-schedule sweep without a per-game epsilon array (sweep_eps)");
+    a.sweep = (a.qi >= 0 && (q_sweep || mx->sweep_noise_prob)) ? 1 : 0;
     const long tuples = (long)c->n_actions[0] * c->n_actions[1];
     if (tuples > kTupMaxTuples) NO("more than 4,096 action pairs");
     a.tuples = (int)tuples; a.T = T;
@@ -1091,6 +1096,8 @@ int thrl_mixed_episodes(const thrl_cfg* c, thrl_mixed* mx, void* q, int32_t* cou
                 t.eps0[i] = a.eps0[i];
             }
             t.q = q; t.counter = counter; t.state = state;
+            t.sw_gamma = mx->sweep_gamma; t.sw_alpha = mx->sweep_alpha; t.sw_eps_end = mx->sweep_eps_end;
+            t.sw_eps_step = mx->sweep_eps_step; t.sw_eps = mx->sweep_eps; t.sw_noise_prob = mx->sweep_noise_prob;
             unsigned char* base = (unsigned char*)mx->policy_tab;
             t.lut = base;
             t.next_game = (int32_t*)(base + kPTupleLutRegion - 64);

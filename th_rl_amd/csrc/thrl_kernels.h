@@ -140,6 +140,11 @@ struct PTupleArgs {
     int32_t buf_len[2], count0[2];
     double eps0[2];
     float* policy_tab;              // HBM CDF rows [G][npid + 1][APAD] (one policy against a QTable)
+    // per-game sweeps of the QTable agent / the env (null = the scalars), [2][G] except noise_prob [G]; `sweep` = the kernel's
+    // sweep variant is needed (a QTable agent in the game and any of them given)
+    const double* sw_gamma; const double* sw_alpha; const double* sw_eps_end; const double* sw_eps_step;
+    double* sw_eps; const double* sw_noise_prob;
+    int32_t sweep;
     double* game_reward_log; double* game_action_log;    // [n_episodes][2][G]
     int32_t* next_game;
     uint64_t seed, game_offset, first_episode;

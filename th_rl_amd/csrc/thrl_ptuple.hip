@@ -42,9 +42,10 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t old, uint32_t val, int lane)
 
 // T: table dtype; NR: number of policy agents (1: the other agent is a QTable; 2: none is); APAD: padded action count of the
 // CDF rows; NSEG: 64-step segments per episode; TLDS: CDF tables in LDS (else HBM scratch)
-template <typename QT, int NR, int APAD, int NSEG, bool TLDS, bool NOISE>
+template <typename QT, int NR, int APAD, int NSEG, bool TLDS, bool NOISE, bool SWEEP>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NR == 1 ? 3 : 4)))
 k_ptuple_episodes(const PTupleArgs a) {
+    static_assert(!SWEEP || (NR == 1 && NOISE), "per-game sweeps: the QTable agent's variant, compiled with the noise path");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -146,6 +147,25 @@ k_ptuple_episodes(const PTupleArgs a) {
         double p_off = price0;
         int off_qp = 0;
         double eps_q = HASQ ? a.eps0[qi] : 0.0;
+        // SWEEP: this game's own alpha / gamma / epsilon schedule of the QTable agent and noise_prob (thrl_mixed.sweep_*), derived
+        // exactly as fill_agents() derives the scalars -- as k_mixed_wave does
+        TdCoef tcq_g = tcq;
+        QT alpha_g = alpha_q, gamma_g = gamma_q, ag_g = ag_q;
+        double eend_g = pq.eps_end, estep_g = pq.eps_step, np_g = a.env.noise_prob;
+        if (SWEEP) {
+            const size_t k = (size_t)qi * (size_t)a.G + (size_t)g;
+            if (a.sw_alpha || a.sw_gamma) {
+                const double ga = a.sw_gamma ? a.sw_gamma[k] : pq.gamma;
+                tcq_g = td_coef(a.sw_alpha ? a.sw_alpha[k] : pq.alpha, ga);
+                alpha_g = std::is_same<QT, float>::value ? (QT)tcq_g.alpha_f : (QT)tcq_g.alpha;
+                gamma_g = (QT)ga;
+                ag_g = std::is_same<QT, float>::value ? (QT)tcq_g.alpha_gamma_f : (QT)0;
+            }
+            if (a.sw_eps) eps_q = a.sw_eps[k];
+            if (a.sw_eps_end) eend_g = a.sw_eps_end[k];
+            if (a.sw_eps_step) estep_g = a.sw_eps_step[k];
+            if (a.sw_noise_prob) np_g = a.sw_noise_prob[g];
+        }
         int cnt[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) cnt[r] = a.count0[a.ri[r]];
@@ -212,7 +232,9 @@ k_ptuple_episodes(const PTupleArgs a) {
                 if (NOISE) {
                     const int tt = min(seg * 64 + lane, T - 1);
                     const u32x4 xn = draw(a.seed, gid, eg, (uint32_t)tt, kStreamNoise);
-                    nzm[seg] = __ballot(seg * 64 + lane < T && u01_32(xn.x) < a.env.noise_prob);
+                    // (a noise_prob sweep moves the probability of a noisy env: with noise_prob 0 in the config there are no draws, as
+                    //  in the other kernels)
+                    nzm[seg] = __ballot(seg * 64 + lane < T && a.env.noise_prob > 0.0 && u01_32(xn.x) < (SWEEP ? np_g : a.env.noise_prob));
                     NA[seg] = __dadd_rn(a.env.noise_lo, __dmul_rn(__dsub_rn(a.env.a, a.env.noise_lo), u01_32(xn.y)));
                 }
             }
@@ -349,7 +371,7 @@ k_ptuple_episodes(const PTupleArgs a) {
                         if (n_off) ns = (uint32_t)min(max(encode64(p_next, pq) - a.row_lo, 0), a.win_rows - 1);
                     }
                     const uint32_t cell = valid ? srow * (uint32_t)Aq + act : 0u;
-                    ops[seg].set(tab[cell], rew[qi], tcq);
+                    ops[seg].set(tab[cell], rew[qi], SWEEP ? tcq_g : tcq);
                     word[seg] = ns | (cell << 8);
                     if (valid && a.counter)
                         __hip_atomic_fetch_add(&hist[cell >> 1], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -389,13 +411,14 @@ k_ptuple_episodes(const PTupleArgs a) {
                         xo.gather(sel, ops[seg], true);
                         const int nb = min(16, T - base_t);
                         const bool cntr = false;                  // (counted lane-parallel in phase (e))
-#define THRL_PT_STEP(J) if ((J) < nb) tup::replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cntr, ag_q, alpha_q, gamma_q);
+#define THRL_PT_STEP(J) if ((J) < nb) tup::replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cntr, SWEEP ? ag_g : ag_q, SWEEP ? alpha_g : alpha_q, SWEEP ? gamma_g : gamma_q);
                         THRL_PT_STEP(0) THRL_PT_STEP(1) THRL_PT_STEP(2) THRL_PT_STEP(3) THRL_PT_STEP(4) THRL_PT_STEP(5) THRL_PT_STEP(6) THRL_PT_STEP(7)
                         THRL_PT_STEP(8) THRL_PT_STEP(9) THRL_PT_STEP(10) THRL_PT_STEP(11) THRL_PT_STEP(12) THRL_PT_STEP(13) THRL_PT_STEP(14) THRL_PT_STEP(15)
 #undef THRL_PT_STEP
                     }
                 }
-                eps_q = __dadd_rn(pq.eps_end, __dmul_rn(__dsub_rn(eps_q, pq.eps_end), pq.eps_step));       // agents.py:78
+                eps_q = SWEEP ? __dadd_rn(eend_g, __dmul_rn(__dsub_rn(eps_q, eend_g), estep_g))
+                              : __dadd_rn(pq.eps_end, __dmul_rn(__dsub_rn(eps_q, pq.eps_end), pq.eps_step));       // agents.py:78
             }
             (void)tau_in;
         }
@@ -424,6 +447,7 @@ k_ptuple_episodes(const PTupleArgs a) {
             }
         }
         if (lane == 0 && a.n_episodes > 0) a.state[g] = (NOISE && off) ? p_off : price_lut[tau];
+        if (SWEEP && HASQ && a.sw_eps && lane == 0) a.sw_eps[(size_t)qi * (size_t)a.G + (size_t)g] = eps_q;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -479,12 +503,12 @@ __global__ void __launch_bounds__(1024) k_ptuple_lut(const PTupleArgs a, unsigne
     }
 }
 
-template <typename QT, int NR, int APAD, bool TLDS, bool NOISE>
+template <typename QT, int NR, int APAD, bool TLDS, bool NOISE, bool SWEEP = false>
 int launch_seg(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
     const int nseg = (a.T + 63) / 64;
 #define THRL_PT_LAUNCH(NS)                                                                                           \
     {                                                                                                                \
-        auto kern = k_ptuple_episodes<QT, NR, APAD, NS, TLDS, NOISE>;                                                \
+        auto kern = k_ptuple_episodes<QT, NR, APAD, NS, TLDS, NOISE, SWEEP>;                                         \
         if (lds > 64 * 1024) {                                                                                       \
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
@@ -508,6 +532,10 @@ int launch_n(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s
 }
 template <typename QT>
 int launch_t(const PTupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
+    if (a.sweep) {                          // (plan_ptuple: only with a QTable agent in the game)
+        int amax = a.ag[a.ri[0]].n_actions;
+        return amax <= 24 ? launch_seg<QT, 1, 24, false, true, true>(a, grid, block, lds, s) : launch_seg<QT, 1, 32, false, true, true>(a, grid, block, lds, s);
+    }
     return a.env.noise_prob > 0.0 ? launch_n<QT, true>(a, grid, block, lds, s) : launch_n<QT, false>(a, grid, block, lds, s);
 }
 
