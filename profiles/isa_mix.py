@@ -26,14 +26,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-# (translation unit, substring of the mangled kernel name, key in the output)
+# (translation unit, regular expression over the mangled kernel name, key in the output)
 KERNELS = [("thrl_wave_f32.hip", "k_wave_episodesIfLi2ELi1ELb0ELb0ELb0ELb0EE", "k_wave_episodes<float,2,1> (headline)"),
            ("thrl_mixed.hip", "k_mixed_waveIfLi1ELi24ELi2ELb0ELi2EE", "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)"),
            ("thrl_mixed.hip", "k_mixed_waveIfLi2ELi24ELi2ELb0ELi1EE", "k_mixed_wave<float,NR=2,24,2,memo> (2 x Reinforce)"),
            ("thrl_nn.hip", "k_nn_reinforce_trainILi24ELb0EE", "k_nn_reinforce_train<24,false>"),
-           ("thrl_ptuple.hip", "k_ptuple_episodesIfLi2ELi24ELi2ELb1ELb0EE", "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)"),
-           ("thrl_ptuple.hip", "k_ptuple_episodesIfLi1ELi24ELi2ELb0ELb0EE", "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"),
-           ("thrl_tuple_f32.hip", "k_tuple_episodesIfLi3ELi1ELb0ELb0EE", "k_tuple_episodes<float,N=3,NSEG=1> (three players)")]
+           ("thrl_ptuple.hip", r"k_ptuple_episodesIfLi2ELi24ELi2ELb1E(Lb0E)*E", "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)"),
+           ("thrl_ptuple.hip", r"k_ptuple_episodesIfLi1ELi24ELi2ELb0E(Lb0E)*E", "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"),
+           ("thrl_tuple_f32.hip", r"k_tuple_episodesIfLi3ELi1E(Lb0E)*E", "k_tuple_episodes<float,N=3,NSEG=1> (three players)")]
 # two-source (or one-source) 32-bit operations measured at the fast price when every source is a VGPR
 FAST_MEASURED = {"v_and_b32", "v_add_u32", "v_mov_b32", "v_add_f32", "v_mul_f32", "v_xor_b32"}
 # same operand form, not measured one by one: assumed fast under the same condition (listed separately in the output)
@@ -51,7 +51,9 @@ def asm_of_kernel(tu, symbol):
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-S", "--cuda-device-only", "-o", out, src],
                               cwd=build.CSRC, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if symbol in l and l.rstrip().split(";")[0].strip().endswith(":") and l.startswith("_Z"))
+    # `symbol` is a regular expression over the mangled name (trailing all-false template flags are written (Lb0E)* so that a
+    # new flag does not break the lookup)
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and l.rstrip().split(";")[0].strip().endswith(":") and re.search(symbol, l))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     meta = {}
     for l in lines[end:end + 400]:
