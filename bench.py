@@ -54,7 +54,8 @@ VALU_F32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: peak FP32 vector
 NN_HIDDEN = 256
 N_SIMD, N_CU = 1024, 256            # MI355X: 256 CUs x 4 SIMD-32
 KEY_WAVE = "k_wave_episodes<float,2,1> (headline)"
-KEY_MIXED = {"rr": "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)", "qr": "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"}
+KEY_MIXED = {"rr": "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)", "qr": "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)",
+             "qa": "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"}
 
 
 def library_info():
@@ -174,7 +175,10 @@ def cpu_baseline_nn(kind, seconds_target=10.0):
     A, lo, hi, gamma = 21, 0.2, 0.4, 0.995
     rng = np.random.RandomState(0)
     n_nn = 2 if kind == "rr" else 1
-    ws = [(rng.uniform(-0.06, 0.06, NN.n_params(A))).astype(np.float32) for _ in range(n_nn)]
+    ac = kind == "qa"                           # ActorCritic: value head, train_net on (s, a, r, s') with its own gamma
+    if ac:
+        gamma = 0.98
+    ws = [(rng.uniform(-0.06, 0.06, NN.ac_n_params(A) if ac else NN.n_params(A))).astype(np.float32) for _ in range(n_nn)]
     ms = [np.zeros_like(w) for w in ws]; vs = [np.zeros_like(w) for w in ws]; st = [0] * n_nn
     mem = [[] for _ in range(n_nn)]
     qcfg, _ = O.cfg_from_config({"agents": [dict(CFG_AGENT, states=1), dict(CFG_AGENT, states=1)],
@@ -182,19 +186,22 @@ def cpu_baseline_nn(kind, seconds_target=10.0):
     price, steps, t0 = 5.0, 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds_target:
         for _ in range(T_STEPS):
-            acts = [int(NN.sample_action(ws[k], A, [price], [rng.uniform()])[0]) for k in range(n_nn)]
+            acts = [int(NN.sample_action(NN.ac_split(ws[k], A)[0] if ac else ws[k], A, [price], [rng.uniform()])[0]) for k in range(n_nn)]
             sc = [NN.scale(a, A, lo, hi) for a in acts]
             if n_nn == 1:                       # a greedy-free stand-in for the tabular opponent's action
                 sc = [lo + (hi - lo) * rng.randint(A) / (A - 1.0)] + sc
             nprice, rew = O.env_step(qcfg, sc)
             for k in range(n_nn):
-                mem[k].append((price, acts[k], rew[k - n_nn]))
+                mem[k].append((price, acts[k], rew[k - n_nn], nprice))
             price = nprice
             steps += 1
         for k in range(n_nn):
             if len(mem[k]) >= 1000:
-                pr, ac, rw = zip(*mem[k])
-                ws[k], ms[k], vs[k], st[k], _ = NN.train_net(ws[k], ms[k], vs[k], st[k], A, pr, ac, rw, gamma, 0.0)
+                pr, aa, rw, npr = zip(*mem[k])
+                if ac:
+                    ws[k], ms[k], vs[k], st[k], _ = NN.ac_train_net(ws[k], ms[k], vs[k], st[k], A, pr, aa, rw, npr, gamma, 0.0)
+                else:
+                    ws[k], ms[k], vs[k], st[k], _ = NN.train_net(ws[k], ms[k], vs[k], st[k], A, pr, aa, rw, gamma, 0.0)
                 mem[k] = []
     wall = time.perf_counter() - t0
     return dict(value=steps / wall, unit="env-steps/s", cores=1, kind="port",
@@ -594,7 +601,7 @@ def main():
             torch.cuda.empty_cache()
             # (warm-up = the timed length: the same launch shapes, so no allocation falls into the timed region)
             out["secondary"] = [run_nn(p, 65536, 40, 40, "fused", 0.0 if args.no_cpu_baseline else min(args.cpu_seconds, 5.0), lib)
-                                for p in ("rr", "qr")]
+                                for p in ("rr", "qr", "qa")]
         emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

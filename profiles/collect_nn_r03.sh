@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence for BASELINE configs[3] (neural policies x 65,536 games): bench lines of the four pairings, and for
-# 2 x Reinforce (rr) and QTable vs Reinforce (qr) the kernel timing + the PMC passes nn_traffic.json is built from.
+# 2 x Reinforce (rr), QTable vs Reinforce (qr) and QTable vs ActorCritic (qa) the kernel timing + the PMC passes nn_traffic.json is built from.
 #   gpurun --timeout 1150 -- 'bash profiles/collect_nn_r03.sh r03nn'
 TAG=${1:-r03nn}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -13,7 +13,7 @@ for p in rr qr qa qc; do
   cut -c1-160 $OUT/${TAG}_${p}_bench.json
 done
 cd /tmp && export TMPDIR=/tmp
-for p in rr qr; do
+for p in rr qr qa; do
   B="$ROOT/bench.py --workload nn --nn-agents $p --steps 40 --warmup 10 --no-cpu-baseline"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${p}_stats -- python3 $B > $OUT/${TAG}_${p}_stats.log 2>&1 || exit 4
   run_pmc () {

@@ -31,6 +31,7 @@ KERNELS = [("thrl_wave_f32.hip", "k_wave_episodesIfLi2ELi1ELb0ELb0ELb0ELb0EE", "
            ("thrl_mixed.hip", "k_mixed_waveIfLi1ELi24ELi2ELb0ELi2EE", "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)"),
            ("thrl_mixed.hip", "k_mixed_waveIfLi2ELi24ELi2ELb0ELi1EE", "k_mixed_wave<float,NR=2,24,2,memo> (2 x Reinforce)"),
            ("thrl_nn.hip", "k_nn_reinforce_trainILi24ELb0EE", "k_nn_reinforce_train<24,false>"),
+           ("thrl_nn.hip", "k_nn_reinforce_trainILi24ELb1EE", "k_nn_reinforce_train<24,true> (ActorCritic)"),
            ("thrl_ptuple.hip", r"k_ptuple_episodesIfLi2ELi24ELi2ELb1E(Lb0E)*E", "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)"),
            ("thrl_ptuple.hip", r"k_ptuple_episodesIfLi1ELi24ELi2ELb0E(Lb0E)*E", "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)"),
            ("thrl_tuple_f32.hip", r"k_tuple_episodesIfLi3ELi1E(Lb0E)*E", "k_tuple_episodes<float,N=3,NSEG=1> (three players)")]

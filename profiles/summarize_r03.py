@@ -118,7 +118,10 @@ ISA_KEY = {("rr", "k_mixed_wave"): "k_mixed_wave<float,NR=2,24,2,memo> (2 x Rein
            ("rr", "k_ptuple_episodes"): "k_ptuple_episodes<float,NR=2,24,2,lds> (2 x Reinforce)",
            ("qr", "k_ptuple_episodes"): "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)",
            ("rr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,false>",
-           ("rr", "k_nn_returns"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_returns"): "k_nn_reinforce_train<24,false>"}
+           ("rr", "k_nn_returns"): "k_nn_reinforce_train<24,false>", ("qr", "k_nn_returns"): "k_nn_reinforce_train<24,false>",
+           ("qa", "k_ptuple_episodes"): "k_ptuple_episodes<float,NR=1,24,2,hbm> (QTable vs Reinforce)",      # (the same kernel: the policy head)
+           ("qa", "k_mixed_wave"): "k_mixed_wave<float,NR=1,24,2,table> (QTable vs Reinforce)",
+           ("qa", "k_nn_reinforce_train"): "k_nn_reinforce_train<24,true> (ActorCritic)"}
 
 
 def nn(tag):
@@ -127,7 +130,7 @@ def nn(tag):
     out = dict(nn=lib.get("nn"), src=lib.get("src"), library=lib, games=Gn, pairings={})
     for p in ("rr", "qr", "qa", "qc"):
         copy_bench(os.path.join(GO, "%s_%s_bench.json" % (tag, p)), "r03_nn%s_bench.json" % p)
-    for p in ("rr", "qr"):
+    for p in ("rr", "qr", "qa"):
         ptag = "%s_%s" % (tag, p)
         copy_stats(ptag, "r03_nn%s_kernel_stats.csv" % p)
         ks = {}
