@@ -460,7 +460,11 @@ def test_kernel_selection_covers_individual_grids_on_the_host(lib):
     a5 = dict(CFG_AGENT, actions=5, states=20, action_range=[0.0, 0.3], min_memory=25)
     assert sel([a21, a21])[0] == "wave"
     k, ws = sel([a11, dict(a21, min_memory=25), a5], max_steps=25)
-    assert k == "tuple" and ws == 160 * 1024
+    # workspace = LUT image + work counter (160 KiB) + the visit log of every resident wave: [32 episodes][25 steps] words of 8 bytes.
+    # 4,096 games fill the persistent grid, so the log's size tells the resident waves per CU: the visit histogram overlays the
+    # tables and G is u16, which leaves 14 waves per CU (it was 8 with both beside the tables)
+    waves, rest = divmod(ws - 160 * 1024, 32 * 25 * 8)
+    assert k == "tuple" and rest == 0 and waves == 14 * 256
     assert sel([a11, dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                 # two agents, different grids
     assert sel([dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                     # one agent
     assert sel([a11, dict(a21, min_memory=25), a5], max_steps=25, noise_prob=0.05)[0] == "tuple"

@@ -263,7 +263,8 @@ struct TuplePlan {
     int waves_per_block, blocks_per_cu;
     size_t lut_image_bytes;
 };
-constexpr size_t kTupleWsBytes = 160 * 1024;       // LUT image (< 128 KiB) + the launch's work counter in the last 64 bytes
+constexpr size_t kTupleWsBytes = 160 * 1024;       // LUT image (< 128 KiB) + the launch's work counter in the last 64 bytes;
+                                                   // the visit log of the resident waves follows (tuple_workspace)
 
 TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     TuplePlan p;
@@ -319,9 +320,18 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     }
     a.am_off = (int)align_up((size_t)elems * esz, 16);
     a.g_off = (int)align_up((size_t)a.am_off + am, 16);
-    a.hist_off = (int)align_up((size_t)a.g_off + 4 * ((size_t)tuples + 1), 16);
     a.hist_dwords = hd;
-    a.game_lds_bytes = (int)align_up((size_t)a.hist_off + 4 * (size_t)hd, 16);
+    if ((size_t)hd * 4 > (size_t)elems * esz) NO("visit histogram does not fit the table region");      // (never: u16 per cell)
+    a.game_lds_bytes = (int)align_up((size_t)a.g_off + 2 * ((size_t)tuples + 1), 16);
+    // action words: agent i's action in a bit field of ceil(log2 A_i) bits; the widths sum to < log2(tuples) + N <= 16
+    int sh = 0;
+    for (int i = 0; i < N; i++) {
+        int bits = 0;
+        while ((1 << bits) < c->n_actions[i]) bits++;
+        a.act_sh[i] = sh; a.act_bits[i] = bits; sh += bits;
+    }
+    if (sh > 16) NO("action word wider than 16 bits");
+    a.vlog_wave_bytes = (int64_t)kTupMaxEpisodes * T * (N <= 2 ? 4 : 8);
     a.aq_off = (int)align_up((size_t)tuples * N * 2, 16);
     a.lut_lds_bytes = a.aq_off + N * 64 * 8 * 2;
     a.price_off = a.lut_lds_bytes;
@@ -348,6 +358,18 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     p.ok = true;
     return p;
 #undef NO
+}
+
+// Workspace of the tuple-chain kernel: [0, kTupleWsBytes) LUT image + work counter, then the visit log of every resident wave
+struct TupleWs { int grid, total_waves; size_t bytes; };
+TupleWs tuple_workspace(const thrl_cfg* c, const TuplePlan& p) {
+    TupleWs w;
+    w.grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
+    const int max_grid = dev_info().cus * p.blocks_per_cu;
+    if (w.grid > max_grid) w.grid = max_grid;
+    w.total_waves = w.grid * p.waves_per_block;
+    w.bytes = kTupleWsBytes + align_up((size_t)w.total_waves * (size_t)p.a.vlog_wave_bytes, 256);
+    return w;
 }
 
 constexpr size_t kLutRegion = 16384;            // workspace bytes reserved for the LUT image
@@ -419,7 +441,8 @@ size_t thrl_replay_mem_bytes(const thrl_cfg* c) {
 size_t thrl_workspace_bytes(const thrl_cfg* c) {
     if (validate(c) != THRL_OK) return 0;
     const WavePlan p = plan_wave(c, nullptr, false);
-    const size_t tuple_ws = plan_tuple(c, nullptr).ok ? kTupleWsBytes : kLutRegion;  // (the generic kernel keeps nothing there)
+    const TuplePlan tp = plan_tuple(c, nullptr);
+    const size_t tuple_ws = tp.ok ? tuple_workspace(c, tp).bytes : kLutRegion;       // (the generic kernel keeps nothing there)
     if (!p.ok) return tuple_ws;
     const size_t wave_ws = wave_workspace(c, p).bytes;                               // (either kernel can be asked for by id)
     return wave_ws > tuple_ws ? wave_ws : tuple_ws;
@@ -619,8 +642,9 @@ static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, Tu
     if (b->inj_u && !b->inj_choice) return fail(THRL_ERR_NULL, "inj_u given without inj_choice");
     if (b->inj_u && c->noise_prob > 0.0 && (!b->inj_noise_u || !b->inj_noise_a))
         return fail(THRL_ERR_NULL, "injected draws with noise_prob > 0 need inj_noise_u / inj_noise_a");
-    if (!b->workspace || b->workspace_bytes < kTupleWsBytes)
-        return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes, kTupleWsBytes);
+    const TupleWs ws = tuple_workspace(c, p);
+    if (!b->workspace || b->workspace_bytes < ws.bytes)
+        return fail(THRL_ERR_WORKSPACE, "workspace too small: have %zu need %zu", b->workspace_bytes, ws.bytes);
     if ((b->reward_log == nullptr) != (b->action_log == nullptr))
         return fail(THRL_ERR_NULL, "reward_log and action_log must both be given or both NULL");
     TupleArgs& a = p.a;
@@ -635,12 +659,11 @@ static int run_tuple(const thrl_cfg* c, const thrl_buffers* b, thrl_run* run, Tu
     unsigned char* lut = (unsigned char*)b->workspace;
     a.lut = lut;
     a.next_game = (int32_t*)((char*)b->workspace + kTupleWsBytes - 64);
+    a.vlog = (char*)b->workspace + kTupleWsBytes;
     a.seed = run->seed; a.game_offset = run->game_offset;
     a.waves_per_block = p.waves_per_block;
-    int grid = (c->n_games + p.waves_per_block - 1) / p.waves_per_block;
-    const int max_grid = dev_info().cus * p.blocks_per_cu;
-    if (grid > max_grid) grid = max_grid;
-    a.total_waves = grid * p.waves_per_block;
+    const int grid = ws.grid;
+    a.total_waves = ws.total_waves;
     const int block = p.waves_per_block * 64;
     const size_t lds = (size_t)a.lut_lds_bytes + (size_t)p.waves_per_block * a.game_lds_bytes;
     int e = launch_tuple_lut(a, lut, s);

@@ -89,11 +89,15 @@ struct TupleArgs {
     int32_t lut_lds_bytes;          // LDS-staged part of the LUT image: rows16 [tuples][N], then aq / sct [N][64] doubles
     int32_t aq_off, price_off;      // byte offsets in the image: aq (inside the staged part), price [tuples] (HBM only)
     int32_t qsum_off;               // total quantity per tuple [tuples] doubles (HBM only; games with env noise)
-    int32_t game_lds_bytes;         // per wave: tables | greedy-action bytes | G table | visit histogram
+    int32_t game_lds_bytes;         // per wave: tables (the visit histogram overlays them after write-back) | greedy-action bytes | G table
     int32_t tab_off[kTupMaxN];      // element offset of agent i's window (+ 2 spill rows) in the per-game table region
     int32_t am_off, am_off_i[kTupMaxN];      // byte offsets
-    int32_t g_off;                  // byte offset of G [tuples + 1] u32
-    int32_t hist_off, hist_off_i[kTupMaxN], hist_dwords;   // histogram: byte offset, per-agent dword offsets, total dwords
+    int32_t g_off;                  // byte offset of G [tuples + 1] u16: the agents' greedy actions as bit fields
+    int32_t act_sh[kTupMaxN], act_bits[kTupMaxN];          // agent i's field in an action word: shift, width = ceil(log2 A_i)
+                                                           // (the widths sum to < log2(tuples) + N <= 16)
+    int32_t hist_off_i[kTupMaxN], hist_dwords;   // histogram (u16 per cell, at the table region's base): per-agent dword offsets, total
+    void* vlog;                     // device: visit log, per wave [n_episodes][T] words of N cells (u16 each; 4 bytes for N <= 2, else 8)
+    int64_t vlog_wave_bytes;        // bytes of one wave's log
     int32_t row_lo[kTupMaxN], win_rows[kTupMaxN];
     int64_t stride;
     EnvParams env;

@@ -24,7 +24,10 @@
 //     lane reads ceil(A_i/16) columns of the next-state row, four DPP steps give the row maximum, lane 16i stores
 //     the TD value; step operands reach the 16-lane rows by ds_bpermute per 16 steps and row_newbcast DPP per step.
 //     Strictly one transition at a time per agent, in order: no hazard analysis needed.
-//   * visit counters: u16 histogram in LDS beside the tables, applied to the int32 counters once per launch.
+//   * visit counters: every step's cells (u16 per agent) go to a per-wave log in HBM / L2 (coalesced, lane = step); after a
+//     game's tables are written back the log is folded into a u16 histogram that OVERLAYS the table region and is applied
+//     to the int32 counters once per launch (as the wave kernel does: no LDS is spent on the histogram).
+//   * action words: the agents' actions as bit fields (ceil(log2 A_i) bits each, < 16 bits in all), so G is u16.
 //   * env noise (template NOISE, noise_prob > 0): a step whose intercept was redrawn (environments.py:29-31) leaves the
 //     action grid.  The state after it is carried as explicit rows (both encodes of its price, computed once on the
 //     chain from qsum[tau] = the tuple's total quantity); the step played in it reads the agents' greedy actions from
@@ -194,9 +197,18 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     unsigned char* game = smem + a.lut_lds_bytes + (size_t)wib * a.game_lds_bytes;
     QT* const tabs = reinterpret_cast<QT*>(game);
     unsigned char* const am = game + a.am_off;
-    uint32_t* const gt = reinterpret_cast<uint32_t*>(game + a.g_off);                                // [tuples + 1]
+    unsigned short* const gt = reinterpret_cast<unsigned short*>(game + a.g_off);                    // [tuples + 1]
     typedef unsigned __attribute__((may_alias)) hist_u32;
-    hist_u32* const hist = reinterpret_cast<hist_u32*>(game + a.hist_off);
+    hist_u32* const hist = reinterpret_cast<hist_u32*>(game);             // overlays the tables once they are back in HBM
+    // visit log of this wave: one word of N u16 cells per step
+    typedef typename std::conditional<(N <= 2), uint32_t, uint64_t>::type VW;
+    VW* const vlog = reinterpret_cast<VW*>(reinterpret_cast<char*>(a.vlog) + ((int64_t)blockIdx.x * a.waves_per_block + wib) * a.vlog_wave_bytes);
+    // action words: agent i's action = bits [sh_i, sh_i + nb_i)
+    int sh[N];
+    uint32_t fm[N], fmask[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { sh[i] = a.act_sh[i]; fm[i] = (1u << a.act_bits[i]) - 1u; fmask[i] = fm[i] << sh[i]; }
+#define THRL_FLD(x, i) (((uint32_t)(x) >> sh[i]) & fm[i])
 
     // replay ("exec") layout: agent my_ag owns the 16-lane row `lane >> 4`
     const int my_ag = lane >> 4, l16 = lane & 15;
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     const int A_me = pme.n_actions;
     const unsigned a_bytes = (unsigned)A_me * (unsigned)sizeof(QT);
     const unsigned tab_me = lds_addr(tabs + a.tab_off[ag_ok ? my_ag : 0]);
-    const unsigned hist_me = lds_addr(hist + a.hist_off_i[ag_ok ? my_ag : 0]);
+    const unsigned hist_me = tab_me;              // (unused: visits are counted from the log)
     const unsigned col_b0 = (unsigned)min(l16, A_me - 1) * (unsigned)sizeof(QT), col_b1 = (unsigned)min(l16 + 16, A_me - 1) * (unsigned)sizeof(QT);
     const unsigned col_b2 = (unsigned)min(l16 + 32, A_me - 1) * (unsigned)sizeof(QT), col_b3 = (unsigned)min(l16 + 48, A_me - 1) * (unsigned)sizeof(QT);
     int amax = 1;
@@ -275,7 +287,6 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 t[(W + 1) * A + lane] = qg[p.table_off + (spill_t[i] >= 0 ? spill_t[i] : 0) * A + lane];
             }
         }
-        for (int k = lane; k < a.hist_dwords; k += 64) hist[k] = 0u;
         __builtin_amdgcn_wave_barrier();
 
         int tau = tuples;                    // current state: action tuple of the last step; `tuples` = the launch's initial state
@@ -330,13 +341,13 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 for (int u = 0; u < 4; u++) {
                     uint32_t packed = 0u;
 #pragma unroll
-                    for (int i = 0; i < N; i++) packed |= (uint32_t)am[a.am_off_i[i] + row[u][i]] << (8 * i);
-                    if (base + u * 64 + lane <= tuples) gt[base + u * 64 + lane] = packed;
+                    for (int i = 0; i < N; i++) packed |= (uint32_t)am[a.am_off_i[i] + row[u][i]] << sh[i];
+                    if (base + u * 64 + lane <= tuples) gt[base + u * 64 + lane] = (unsigned short)packed;
                 }
             }
             __builtin_amdgcn_wave_barrier();
 
-            // ---- (c) draws, lane = step: Mw byte i = 0xFF where agent i explores, Cw byte i = its random choice
+            // ---- (c) draws, lane = step: Mw field i = all ones where agent i explores, Cw field i = its random choice
             uint32_t Mw[NSEG], Cw[NSEG];
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
@@ -354,8 +365,8 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         u = u01_32((i & 1) ? x.z : x.x);
                         ch = __umulhi((i & 1) ? x.w : x.y, (uint32_t)p.n_actions);
                     }
-                    if (u < ((SWEEP && a.sw_eps) ? epsg[i] : a.eps[e][i])) mw |= 0xFFu << (8 * i);
-                    cw |= ch << (8 * i);
+                    if (u < ((SWEEP && a.sw_eps) ? epsg[i] : a.eps[e][i])) mw |= fmask[i];
+                    cw |= ch << sh[i];
                 }
                 Mw[seg] = mw; Cw[seg] = cw;
             }
@@ -394,7 +405,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     if (NOISE && off) {
                         uint32_t wv = 0u;
 #pragma unroll
-                        for (int i = 0; i < N; i++) wv |= (uint32_t)am[a.am_off_i[i] + (int)((offp >> (8 * i)) & 0xFFu)] << (8 * i);
+                        for (int i = 0; i < N; i++) wv |= (uint32_t)am[a.am_off_i[i] + (int)((offp >> (8 * i)) & 0xFFu)] << sh[i];
                         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
                     } else {
                         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
@@ -406,7 +417,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     if (NOISE) asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(acts[seg]) : "s"(ap), "s"(tl));
                     int nt = 0;
 #pragma unroll
-                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)((ap >> (8 * i)) & 0xFFu);
+                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)THRL_FLD(ap, i);
                     tau = nt;
                     if (NOISE) {
                         off = (nzm[seg] >> tl) & 1ull;
@@ -455,11 +466,12 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 }
                 uint32_t ap;
                 double price;
+                VW vw = 0;
                 if (NOISE) {
                     ap = acts[seg];
                     int nt = 0;
 #pragma unroll
-                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)((ap >> (8 * i)) & 0xFFu);
+                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)THRL_FLD(ap, i);
                     if (!valid) nt = 0;
                     price = price_lut[nt];
                     if (n_off) {
@@ -475,7 +487,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 for (int i = 0; i < N; i++) {
                     const AgentParams& p = a.ag[i];
                     const int A = p.n_actions;
-                    const uint32_t act = valid ? ((ap >> (8 * i)) & 0xFFu) : 0u;
+                    const uint32_t act = valid ? THRL_FLD(ap, i) : 0u;
                     uint32_t srow, ns;
                     if (NOISE) {
                         srow = s_off ? ((tq >> (8 * i)) & 0xFFu) : (uint32_t)(rows16[(s_off ? 0u : tq) * N + i] >> 8);
@@ -491,11 +503,9 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     ops[seg][i].set(ov, re, SWEEP ? tcs[i] : td_coef(p));
                     word[seg][i] = ns | (cell << 8);
                     if (valid) { lr[i] += re; la[i] += lut_sct[i * 64 + act]; }
-                    // visit counter of the transition (agents.py:76), lane-parallel (the replay keeps only what is serial)
-                    if (valid && a.counter)
-                        __hip_atomic_fetch_add(&hist[a.hist_off_i[i] + (cell >> 1)], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    vw |= (VW)cell << (16 * i);            // visit counter of the transition (agents.py:76): logged, counted after the launch's last episode
                 }
+                if (valid && a.counter) vlog[e * T + tt] = vw;
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -554,7 +564,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             for (int i = 0; i < N; i++) a.sw_eps[(size_t)i * (size_t)a.G + (size_t)g] = epsg[i];
         }
 
-        // ---- tables back to HBM, env state, visit counters
+        // ---- tables back to HBM, env state
 #pragma unroll
         for (int i = 0; i < N; i++) {
             const AgentParams& p = a.ag[i];
@@ -566,7 +576,37 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 if (spill_p[i] >= 0) qg[p.table_off + spill_p[i] * A + lane] = t[W * A + lane];
                 if (spill_t[i] >= 0) qg[p.table_off + spill_t[i] * A + lane] = t[(W + 1) * A + lane];
             }
-            if (a.counter) {
+        }
+        // ---- visit counters (agents.py:76).  The tables are back in HBM, so their LDS region is free: fold the launch's visit
+        //      log into a u16 histogram there (E*T <= 32*256 < 65536: no carry) and apply it with plain coalesced read-add-write
+        //      (a game's counters belong to this wave alone: no global atomics)
+        if (a.counter) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (int k = lane; k < a.hist_dwords; k += 64) hist[k] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            const int total = a.n_episodes * T;
+            for (int k0 = 0; k0 < total; k0 += 512) {          // eight loads in flight (L2-served: the wave reads what it stored itself)
+                VW w[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    w[j] = __hip_atomic_load(&vlog[min(k0 + j * 64 + lane, total - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (k0 + j * 64 + lane < total) {
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            const unsigned cell = (unsigned)(w[j] >> (16 * i)) & 0xFFFFu;
+                            __hip_atomic_fetch_add(&hist[a.hist_off_i[i] + (cell >> 1)], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const AgentParams& p = a.ag[i];
+                const int A = p.n_actions, W = a.win_rows[i], lo = a.row_lo[i];
                 int32_t* cg = a.counter + (int64_t)g * a.stride + p.table_off;
                 const hist_u32* h = hist + a.hist_off_i[i];
                 for (int k = lane; k < W * A; k += 64) {
@@ -580,6 +620,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     if (grow >= 0 && n) cg[grow * A + col] += (int32_t)n;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
         if (lane == 0 && a.n_episodes > 0) a.state[g] = (NOISE && off) ? p_off : price_lut[tau];
         __builtin_amdgcn_wave_barrier();
@@ -617,6 +658,7 @@ static int launch_tuple_n(const TupleArgs& a, int grid, int block, size_t lds, h
     THRL_TUP_LAUNCH(4)
 #undef THRL_TUP_LAUNCH
 }
+#undef THRL_FLD
 
 template <typename QT, bool NOISE, bool SWEEP>
 static int launch_tuple_t(const TupleArgs& a, int grid, int block, size_t lds, hipStream_t s) {
