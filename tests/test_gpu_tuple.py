@@ -294,3 +294,25 @@ def test_tuple_kernel_sweeps_vs_oracle(dtype, noise):
     q2, st2, cn2 = q0.copy(), s0.copy(), np.zeros(q0.shape, np.int32)
     O.episodes(cfg, q2, cn2, st2, eps_start, O.Memory(cfg), E, seed=31, sweep=dict(gamma=osw["gamma"], alpha=osw["alpha"]))
     assert np.array_equal(part.tables_numpy(), q2) and np.array_equal(part.counters_numpy(), cn2)
+
+
+@pytest.mark.parametrize("label,dtype,noise", [("f32", "float32", 0.0), ("f32_noise05", "float32", 0.05), ("f64", "float64", 0.0)])
+def test_tuple_65536_games_one_32_episode_launch_oracle_slices(label, dtype, noise):
+    """The measured shape (profiles/exp_tuple.py: three players x 65,536 games, ONE launch of 32 episodes, counters on; every
+    resident wave plays ~18 games, so the visit log and the histogram overlay are reused game after game), then four slices of
+    1,024 games against the oracle -- Philox is keyed by the global game id, so a slice is a run of its own with game_offset =
+    its first game: tables, visit counters and env state bit for bit; every agent's counters sum to the transitions played."""
+    config = {"agents": THREE["agents"], "environment": dict(THREE["environment"], noise_prob=noise)}
+    G, E, n = 65536, 32, 1024
+    gb = _batch(config, G, dtype=dtype, kernel="tuple", seed=5, game_offset=1 << 22).init_tables()
+    slices = [(lo, n) for lo in (0, 21000 + 5, 43210, G - n)]
+    q_init = [gb.q[lo:lo + n].cpu().numpy() for lo, _ in slices]
+    s_init = [gb.state[lo:lo + n].cpu().numpy() for lo, _ in slices]
+    out = gb.run(E)
+    assert out["kernel"] == "tuple"
+    for (lo, _), q0, s0 in zip(slices, q_init, s_init):
+        q, c, s, eps, oo = _oracle(config, n, dtype, q0, s0, E, seed=5, game_offset=gb.game_offset + lo)
+        assert np.array_equal(gb.q[lo:lo + n].cpu().numpy(), q), "tables of games %d..%d" % (lo, lo + n)
+        assert np.array_equal(gb.counter[lo:lo + n].cpu().numpy(), c), "counters of games %d..%d" % (lo, lo + n)
+        assert np.array_equal(gb.state[lo:lo + n].cpu().numpy(), s), "states of games %d..%d" % (lo, lo + n)
+    assert bool((gb.counter.sum(dim=1) == 3 * E * 25).all())

@@ -332,7 +332,7 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     }
     if (sh > 16) NO("action word wider than 16 bits");
     a.vlog_wave_bytes = (int64_t)kTupMaxEpisodes * T * (N <= 2 ? 4 : 8);
-    a.aq_off = (int)align_up((size_t)tuples * N * 2, 16);
+    a.aq_off = (int)align_up((size_t)tuples * 8, 16);           // prow [tuples] u32, trow [tuples] u32
     a.lut_lds_bytes = a.aq_off + N * 64 * 8 * 2;
     a.price_off = a.lut_lds_bytes;
     a.qsum_off = a.price_off + 8 * (int)tuples;
@@ -356,6 +356,9 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     if (best_w == 0) NO("tables of one game do not fit LDS");
     p.waves_per_block = best_w; p.blocks_per_cu = best_b;
     p.ok = true;
+    if (getenv("THRL_DEBUG_PLAN"))
+        fprintf(stderr, "plan_tuple: lut_lds %d game_lds %d (tables %d) waves/block %d blocks/cu %d\n", a.lut_lds_bytes, a.game_lds_bytes,
+                a.am_off, best_w, best_b);
     return p;
 #undef NO
 }

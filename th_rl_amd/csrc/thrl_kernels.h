@@ -86,7 +86,7 @@ constexpr int kTupMaxTuples = 4096;
 struct TupleArgs {
     int32_t G, N, T, n_episodes, tuples;
     int32_t waves_per_block, total_waves;
-    int32_t lut_lds_bytes;          // LDS-staged part of the LUT image: rows16 [tuples][N], then aq / sct [N][64] doubles
+    int32_t lut_lds_bytes;          // LDS-staged part of the LUT image: prow / trow [tuples] u32 each, then aq / sct [N][64] doubles
     int32_t aq_off, price_off;      // byte offsets in the image: aq (inside the staged part), price [tuples] (HBM only)
     int32_t qsum_off;               // total quantity per tuple [tuples] doubles (HBM only; games with env noise)
     int32_t game_lds_bytes;         // per wave: tables (the visit histogram overlays them after write-back) | greedy-action bytes | G table

@@ -4,7 +4,7 @@
 
 namespace thrl {
 
-// LUT image: rows16 [tuples][N] (play row | train row << 8, window-local), aq [N][64], sct [N][64], price [tuples],
+// LUT image: prow [tuples] u32 (window-local play rows, byte i = agent i), trow [tuples] u32 (train rows), aq [N][64], sct [N][64], price [tuples],
 // qsum [tuples] (total quantity of the tuple: the price under a redrawn intercept is max(0, a' - b * qsum))
 __global__ void __launch_bounds__(256) k_tuple_lut(const TupleArgs a, unsigned char* out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,12 +20,15 @@ __global__ void __launch_bounds__(256) k_tuple_lut(const TupleArgs a, unsigned c
         double Q = 0.0;
         for (int i = 0; i < N; i++) Q = __dadd_rn(Q, __dmul_rn(a.env.ratio, scaled[i]));          // as env_step sums it
         reinterpret_cast<double*>(out + a.qsum_off)[idx] = Q;
+        uint32_t pw = 0u, tw = 0u;
         for (int i = 0; i < N; i++) {
             const int W = a.win_rows[i];
             const int rp = min(max(encode32(price, a.ag[i]) - a.row_lo[i], 0), W - 1);     // play row (trainer.py:53)
             const int rt = min(max(encode64(price, a.ag[i]) - a.row_lo[i], 0), W - 1);     // train row (agents.py:62,66)
-            reinterpret_cast<unsigned short*>(out)[idx * N + i] = (unsigned short)(rp | (rt << 8));
+            pw |= (uint32_t)rp << (8 * i); tw |= (uint32_t)rt << (8 * i);
         }
+        reinterpret_cast<uint32_t*>(out)[idx] = pw;
+        reinterpret_cast<uint32_t*>(out)[a.tuples + idx] = tw;
     }
     if (idx < N * 64) {
         const int i = idx >> 6, k = idx & 63;

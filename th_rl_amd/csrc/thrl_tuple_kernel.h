@@ -10,8 +10,8 @@
 //
 // Idea: without noise the state after a step is a function of that step's ACTION TUPLE, so a game's state is a
 // small integer tau = ((a0*A1 + a1)*A2 + a2)*A3 + a3 (< 4,096) and everything the loop needs is a table over it:
-//   * per block, staged in LDS once: rows16[tau][i] = window-local row of the price after tuple tau for agent i
-//     (play row: float32 encode, trainer.py:53 | train row: float64 encode, agents.py:62,66 -- both kept);
+//   * per block, staged in LDS once: prow[tau] / trow[tau] = the window-local rows of the price after tuple tau, byte i =
+//     agent i (play rows: float32 encode, trainer.py:53; train rows: float64 encode, agents.py:62,66 -- both kept);
 //     per-action quantities (a/b)*scale_i(k) and scale_i(k)/T; the price per tuple stays in HBM (L2), it is only
 //     gathered lane-parallel;
 //   * per game and episode: the greedy action of every table row (lane = row; tables are frozen during play), composed
@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         for (int k = threadIdx.x; k < (a.lut_lds_bytes >> 2); k += blockDim.x) dst[k] = src[k];
     }
     __syncthreads();
-    const unsigned short* rows16 = reinterpret_cast<const unsigned short*>(smem);                  // [tuples][N]
+    const uint32_t* prow = reinterpret_cast<const uint32_t*>(smem);                                  // [tuples] play rows, byte i = agent i
+    const uint32_t* trow = prow + tuples;                                                            // [tuples] train rows
     const double* lut_aq = reinterpret_cast<const double*>(smem + a.aq_off);                        // [N][64]
     const double* lut_sct = lut_aq + N * 64;                                                         // [N][64]
     const double* price_lut = reinterpret_cast<const double*>(a.lut + a.price_off);                 // [tuples], HBM / L2
@@ -296,11 +297,10 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         bool off = NOISE;
         uint32_t offp = 0u, offt = 0u;
         double p_off = price0;
-        if (NOISE) {
-            tau = 0;
+        uint32_t init_pw = 0u, init_tw = 0u;          // the initial state's rows, packed as prow / trow are
 #pragma unroll
-            for (int i = 0; i < N; i++) { offp |= (uint32_t)init_play[i] << (8 * i); offt |= (uint32_t)init_train[i] << (8 * i); }
-        }
+        for (int i = 0; i < N; i++) { init_pw |= (uint32_t)init_play[i] << (8 * i); init_tw |= (uint32_t)init_train[i] << (8 * i); }
+        if (NOISE) { tau = 0; offp = init_pw; offt = init_tw; }
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
 
@@ -330,18 +330,18 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             __builtin_amdgcn_wave_barrier();
             // ---- (b) G[tau] = the agents' greedy actions in state tau, one per byte (entry `tuples`: the initial state)
             for (int base = 0; base <= tuples; base += 256) {         // four batches of 64 tuples in flight
-                int row[4][N];
+                uint32_t pw[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int tq = min(base + u * 64 + lane, tuples);
-#pragma unroll
-                    for (int i = 0; i < N; i++) row[u][i] = tq == tuples ? init_play[i] : (int)(rows16[tq * N + i] & 0xFFu);
+                    pw[u] = prow[tq];                           // (entry `tuples` reads the next table: replaced below)
+                    if (tq == tuples) pw[u] = init_pw;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     uint32_t packed = 0u;
 #pragma unroll
-                    for (int i = 0; i < N; i++) packed |= (uint32_t)am[a.am_off_i[i] + row[u][i]] << sh[i];
+                    for (int i = 0; i < N; i++) packed |= (uint32_t)am[a.am_off_i[i] + (int)((pw[u] >> (8 * i)) & 0xFFu)] << sh[i];
                     if (base + u * 64 + lane <= tuples) gt[base + u * 64 + lane] = (unsigned short)packed;
                 }
             }
@@ -483,19 +483,21 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     ap = (Cw[seg] & Mw[seg]) | (w & ~Mw[seg]);
                     price = price_lut[nxt];
                 }
+                // train rows of my state and of the state after my step, byte i = agent i
+                uint32_t sw, nw;
+                if (NOISE) {
+                    sw = trow[s_off ? 0u : tq]; if (s_off) sw = tq;
+                    nw = trow[n_off ? 0u : nxt]; if (n_off) nw = nxt;
+                } else {
+                    sw = trow[tq]; if (tq == (uint32_t)tuples) sw = init_tw;       // (entry `tuples` reads the start of aq: replaced)
+                    nw = trow[nxt];
+                }
 #pragma unroll
                 for (int i = 0; i < N; i++) {
                     const AgentParams& p = a.ag[i];
                     const int A = p.n_actions;
                     const uint32_t act = valid ? THRL_FLD(ap, i) : 0u;
-                    uint32_t srow, ns;
-                    if (NOISE) {
-                        srow = s_off ? ((tq >> (8 * i)) & 0xFFu) : (uint32_t)(rows16[(s_off ? 0u : tq) * N + i] >> 8);
-                        ns = n_off ? ((nxt >> (8 * i)) & 0xFFu) : (uint32_t)(rows16[(n_off ? 0u : nxt) * N + i] >> 8);
-                    } else {
-                        srow = tq == (uint32_t)tuples ? (uint32_t)init_train[i] : (uint32_t)(rows16[tq * N + i] >> 8);
-                        ns = (uint32_t)(rows16[nxt * N + i] >> 8);
-                    }
+                    const uint32_t srow = (sw >> (8 * i)) & 0xFFu, ns = (nw >> (8 * i)) & 0xFFu;
                     const uint32_t cell = valid ? srow * (uint32_t)A + act : 0u;
                     const double aq = lut_aq[i * 64 + act];
                     const double re = __dmul_rn(price, aq);                       // environments.py:33
