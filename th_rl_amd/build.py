@@ -57,10 +57,10 @@ def source_hash(files=None):
     return h.hexdigest()[:12]
 
 
-def build(force=False, verbose=False, ablate=0, out=None):
+def build(force=False, verbose=False, ablate=0, out=None, ablate_tuple=0):
     """Each source is compiled to an object in parallel (one hipcc per source), then linked."""
     lib = os.path.abspath(out) if out else LIB
-    if not force and not ablate and up_to_date(lib):
+    if not force and not ablate and not ablate_tuple and up_to_date(lib):
         return lib
     import concurrent.futures
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -76,8 +76,10 @@ def build(force=False, verbose=False, ablate=0, out=None):
         flags = list(cflags)
         if ablate and src == "thrl_wave_f32.hip":
             flags.append("-DTHRL_ABLATE=%d" % ablate)
+        if ablate_tuple and src == "thrl_tuple_f32.hip":
+            flags.append("-DTHRL_TUP_ABLATE=%d" % ablate_tuple)
         if src == "thrl_api.hip":           # thrl_build_info(): which binary is this
-            flags += ["-DTHRL_BUILD_ABLATE=%d" % ablate, '-DTHRL_SRC_HASH="%s"' % src_hash,
+            flags += ["-DTHRL_BUILD_ABLATE=%d" % (ablate | (ablate_tuple << 16)), '-DTHRL_SRC_HASH="%s"' % src_hash,
                       '-DTHRL_WAVE_HASH="%s"' % wave_hash, '-DTHRL_NN_HASH="%s"' % nn_hash]
         key = hashlib.sha1((" ".join(flags) + hipcc).encode()).hexdigest()[:10]
         obj = os.path.join(OBJ_DIR, "%s-%s.o" % (src.replace(".hip", ""), key))
@@ -101,6 +103,7 @@ if __name__ == "__main__":
     ab, outp = 0, None
     if "--ablate" in sys.argv:
         ab = int(sys.argv[sys.argv.index("--ablate") + 1], 0)
+    abt = int(sys.argv[sys.argv.index("--ablate-tuple") + 1], 0) if "--ablate-tuple" in sys.argv else 0
     if "--out" in sys.argv:
         outp = sys.argv[sys.argv.index("--out") + 1]
-    print("built", build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate=ab, out=outp))
+    print("built", build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate=ab, out=outp, ablate_tuple=abt))

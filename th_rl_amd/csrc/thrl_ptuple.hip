@@ -80,11 +80,13 @@ k_ptuple_episodes(const PTupleArgs a) {
     const int Aq = pq.n_actions;
     const int l16 = lane & 15;
     const unsigned a_bytes = (unsigned)Aq * (unsigned)sizeof(QT);
-    const unsigned tab_me = lds_addr(tab), hist_me = lds_addr(hist);
+    const unsigned tab_me = lds_addr(tab);
     const unsigned col_b0 = (unsigned)min(l16, Aq - 1) * (unsigned)sizeof(QT), col_b1 = (unsigned)min(l16 + 16, Aq - 1) * (unsigned)sizeof(QT);
     const unsigned col_b2 = (unsigned)min(l16 + 32, Aq - 1) * (unsigned)sizeof(QT), col_b3 = (unsigned)min(l16 + 48, Aq - 1) * (unsigned)sizeof(QT);
     const int ncol = (Aq + 15) >> 4;
     const bool storer = HASQ && lane == 0;
+    const unsigned long long smask = __ballot(storer);
+    const unsigned tc0 = tab_me + col_b0, tc1 = tab_me + col_b1, tc2 = tab_me + col_b2, tc3 = tab_me + col_b3;
     const TdCoef tcq = td_coef(pq);
     const QT alpha_q = std::is_same<QT, float>::value ? (QT)tcq.alpha_f : (QT)tcq.alpha;
     const QT gamma_q = (QT)pq.gamma;
@@ -317,7 +319,7 @@ k_ptuple_episodes(const PTupleArgs a) {
             const int tau_end = tau;
 
             // ---- (e) lane-parallel over the steps: prices, rewards, ring appends, the QTable agent's snapshot; logs
-            uint32_t word[NSEG];
+            uint32_t wr[NSEG], wc[NSEG];           // byte offsets inside the table: next-state row, rewritten cell
             Ops<QT> ops[NSEG];
             double acc = 0.0;                            // lane k < 4: reward of agent k (k < 2), scaled action of agent k - 2
             double p_carry = 0.0;                        // NOISE: the price after the previous segment's last step
@@ -372,7 +374,8 @@ k_ptuple_episodes(const PTupleArgs a) {
                     }
                     const uint32_t cell = valid ? srow * (uint32_t)Aq + act : 0u;
                     ops[seg].set(tab[cell], rew[qi], SWEEP ? tcq_g : tcq);
-                    word[seg] = ns | (cell << 8);
+                    wr[seg] = ns * a_bytes;
+                    wc[seg] = cell * (uint32_t)sizeof(QT);
                     if (valid && a.counter)
                         __hip_atomic_fetch_add(&hist[cell >> 1], 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
@@ -406,15 +409,16 @@ k_ptuple_episodes(const PTupleArgs a) {
                         const int base_t = seg * 64 + b * 16;
                         if (base_t >= T) break;
                         const unsigned sel = (unsigned)(b * 16 + l16) << 2;
-                        const uint32_t xw = bperm(sel, word[seg]);
+                        const uint32_t xr = bperm(sel, wr[seg]), xc = bperm(sel, wc[seg]);
                         Ops<QT> xo = ops[seg];
                         xo.gather(sel, ops[seg], true);
                         const int nb = min(16, T - base_t);
-                        const bool cntr = false;                  // (counted lane-parallel in phase (e))
-#define THRL_PT_STEP(J) if ((J) < nb) tup::replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cntr, SWEEP ? ag_g : ag_q, SWEEP ? alpha_g : alpha_q, SWEEP ? gamma_g : gamma_q);
-                        THRL_PT_STEP(0) THRL_PT_STEP(1) THRL_PT_STEP(2) THRL_PT_STEP(3) THRL_PT_STEP(4) THRL_PT_STEP(5) THRL_PT_STEP(6) THRL_PT_STEP(7)
-                        THRL_PT_STEP(8) THRL_PT_STEP(9) THRL_PT_STEP(10) THRL_PT_STEP(11) THRL_PT_STEP(12) THRL_PT_STEP(13) THRL_PT_STEP(14) THRL_PT_STEP(15)
-#undef THRL_PT_STEP
+                        const QT agx = SWEEP ? ag_g : ag_q, alx = SWEEP ? alpha_g : alpha_q, gax = SWEEP ? gamma_g : gamma_q;
+#define THRL_PT_BLOCK(NC)                                                                                                          \
+                        if (nb == 16) tup::replay_block<QT, NC, true>(nb, xr, xc, xo, tab_me, tc0, tc1, tc2, tc3, storer, smask, agx, alx, gax); \
+                        else tup::replay_block<QT, NC, false>(nb, xr, xc, xo, tab_me, tc0, tc1, tc2, tc3, storer, smask, agx, alx, gax);
+                        if (ncol == 1) { THRL_PT_BLOCK(1) } else if (ncol == 2) { THRL_PT_BLOCK(2) } else { THRL_PT_BLOCK(4) }
+#undef THRL_PT_BLOCK
                     }
                 }
                 eps_q = SWEEP ? __dadd_rn(eend_g, __dmul_rn(__dsub_rn(eps_q, eend_g), estep_g))

@@ -38,8 +38,16 @@
 #include <type_traits>
 #include "thrl_kernels.h"
 
+// THRL_TUP_ABLATE: timing-only diagnostic builds (python -m th_rl_amd.build --ablate-tuple MASK --out ..., profiles/ablate_tuple.py):
+// a phase is skipped, the results are wrong by construction; thrl_ablate_mask() reports it and bench.py refuses such a library.
+//   1 replay  2 play chain  4 G table  8 draws  16 per-row argmax  32 visit log + counters  64 log sums
+#ifndef THRL_TUP_ABLATE
+#define THRL_TUP_ABLATE 0
+#endif
+
 namespace thrl {
 namespace tup {
+constexpr int kTupAblate = THRL_TUP_ABLATE;
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -151,30 +159,140 @@ template <> struct Ops<double> {
     }
 };
 
-// one transition of every agent (agents.py:68-76): J = position inside the 16-step block (row_newbcast lane)
-template <typename QT, int J>
-__device__ __forceinline__ void replay_step(uint32_t xw, const Ops<QT>& xo, unsigned tab_me, unsigned hist_me, unsigned a_bytes, unsigned col_b0,
-                                            unsigned col_b1, unsigned col_b2, unsigned col_b3, int ncol, bool storer, bool count,
-                                            QT alpha_gamma, QT alpha, QT gamma) {
-    const uint32_t w = dpp32<0x150 + J>(xw);                    // this row's agent, step J of the block: ns | cell << 8
-    const Ops<QT> o = xo.template bcast<J>();
-    const unsigned ns = w & 0xFFu, cell = (w >> 8) & 0xFFFFu;
-    const unsigned rowa = tab_me + ns * a_bytes;
-    QT m = lds_load<QT>(rowa + col_b0);
-    if (ncol > 1) m = m > lds_load<QT>(rowa + col_b1) ? m : lds_load<QT>(rowa + col_b1);
-    if (ncol > 2) { const QT v = lds_load<QT>(rowa + col_b2); m = v > m ? v : m; }
-    if (ncol > 3) { const QT v = lds_load<QT>(rowa + col_b3); m = v > m ? v : m; }
-    m = row16_allmax(m);
-    const QT val = o.value(m, alpha_gamma, alpha, gamma);
-    if (storer) {
-        lds_store<QT>(tab_me + cell * (unsigned)sizeof(QT), val);
-        if (count) {
-            typedef __attribute__((address_space(3))) unsigned lds_u32;
-            __hip_atomic_fetch_add((lds_u32*)(uintptr_t)(hist_me + (cell >> 1) * 4u), 1u << ((cell & 1u) << 4), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
+// One transition of every agent (agents.py:68-76): J = position inside the 16-step block (row_newbcast lane).
+// xr / xc: byte offsets of the next-state row and of the rewritten cell inside the agent's table, lane l16 = step l16 of the
+// block; NC = columns per lane (ceil(max A / 16)); tc0..tc3 = tab_me + the lane's column offsets.
+// float: hand-written.  hipcc neither folds a DPP move into its user nor drops the canonicalising v_max of fmaxf (35 vector
+// instructions per transition as C++); here the row_newbcast broadcasts ride on the address adds, the four steps of the
+// 16-lane maximum are single v_max_f32_dpp, and the store swaps EXEC instead of branching: 11-15 vector instructions.  The
+// s_mov / s_nop pairs are the two wait states a DPP read of a just-written VGPR needs (hipcc does not look inside asm, and it
+// may have copied an operand right before it).  Same arithmetic: first-max select over the lane's columns, maximum over the
+// row, fma(alpha * gamma, max, c1).
+template <int J, int NC>
+__device__ __forceinline__ void replay_step_f32(uint32_t xr, uint32_t xc, uint32_t xc1, unsigned tab_me, unsigned tc0, unsigned tc1, unsigned tc2,
+                                                unsigned tc3, float alpha_gamma, unsigned long long smask) {
+    unsigned t0, t1, t2, t3, sa;
+    float m, v1, v2, v3, c;
+    unsigned long long save;
+    if (NC == 1) {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\ts_nop 0\n\t"
+            "v_add_u32_dpp %[t0], %[xr], %[tc0] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %[sa], %[xc], %[tab] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "ds_read_b32 %[m], %[t0]\n\t"
+            "v_mov_b32_dpp %[c], %[xc1] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_mov_b64 exec, %[mask]\n\t"
+            "v_fmac_f32 %[c], %[ag], %[m]\n\t"
+            "ds_write_b32 %[sa], %[c]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(save), [t0] "=&v"(t0), [sa] "=&v"(sa), [m] "=&v"(m), [c] "=&v"(c)
+            : [xr] "v"(xr), [xc] "v"(xc), [xc1] "v"(xc1), [tab] "v"(tab_me), [tc0] "v"(tc0), [ag] "v"(alpha_gamma), [mask] "s"(smask), [j] "n"(J)
+            : "memory");
+    } else if (NC == 2) {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\ts_nop 0\n\t"
+            "v_add_u32_dpp %[t0], %[xr], %[tc0] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %[t1], %[xr], %[tc1] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "ds_read_b32 %[m], %[t0]\n\t"
+            "ds_read_b32 %[v1], %[t1]\n\t"
+            "v_add_u32_dpp %[sa], %[xc], %[tab] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %[c], %[xc1] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_f32 vcc, %[v1], %[m]\n\t"
+            "v_cndmask_b32 %[m], %[m], %[v1], vcc\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_mov_b64 exec, %[mask]\n\t"
+            "v_fmac_f32 %[c], %[ag], %[m]\n\t"
+            "ds_write_b32 %[sa], %[c]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1), [sa] "=&v"(sa), [m] "=&v"(m), [v1] "=&v"(v1), [c] "=&v"(c)
+            : [xr] "v"(xr), [xc] "v"(xc), [xc1] "v"(xc1), [tab] "v"(tab_me), [tc0] "v"(tc0), [tc1] "v"(tc1), [ag] "v"(alpha_gamma),
+              [mask] "s"(smask), [j] "n"(J)
+            : "memory", "vcc");
+    } else {
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\ts_nop 0\n\t"
+            "v_add_u32_dpp %[t0], %[xr], %[tc0] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %[t1], %[xr], %[tc1] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %[t2], %[xr], %[tc2] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_u32_dpp %[t3], %[xr], %[tc3] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "ds_read_b32 %[m], %[t0]\n\t"
+            "ds_read_b32 %[v1], %[t1]\n\t"
+            "ds_read_b32 %[v2], %[t2]\n\t"
+            "ds_read_b32 %[v3], %[t3]\n\t"
+            "v_add_u32_dpp %[sa], %[xc], %[tab] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %[c], %[xc1] row_newbcast:%[j] row_mask:0xf bank_mask:0xf\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_f32 vcc, %[v1], %[m]\n\t"
+            "v_cndmask_b32 %[m], %[m], %[v1], vcc\n\t"
+            "v_cmp_gt_f32 vcc, %[v2], %[m]\n\t"
+            "v_cndmask_b32 %[m], %[m], %[v2], vcc\n\t"
+            "v_cmp_gt_f32 vcc, %[v3], %[m]\n\t"
+            "v_cndmask_b32 %[m], %[m], %[v3], vcc\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %[m], %[m], %[m] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_mov_b64 exec, %[mask]\n\t"
+            "v_fmac_f32 %[c], %[ag], %[m]\n\t"
+            "ds_write_b32 %[sa], %[c]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [save] "=&s"(save), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sa] "=&v"(sa), [m] "=&v"(m), [v1] "=&v"(v1),
+              [v2] "=&v"(v2), [v3] "=&v"(v3), [c] "=&v"(c)
+            : [xr] "v"(xr), [xc] "v"(xc), [xc1] "v"(xc1), [tab] "v"(tab_me), [tc0] "v"(tc0), [tc1] "v"(tc1), [tc2] "v"(tc2), [tc3] "v"(tc3),
+              [ag] "v"(alpha_gamma), [mask] "s"(smask), [j] "n"(J)
+            : "memory", "vcc");
     }
+}
+
+// the same in C++ for float64 tables (the reference's four separately rounded operations per TD value)
+template <int J, int NC>
+__device__ __forceinline__ void replay_step_f64(uint32_t xr, uint32_t xc, const Ops<double>& xo, unsigned tab_me, unsigned tc0, unsigned tc1, unsigned tc2,
+                                                unsigned tc3, bool storer, double alpha, double gamma) {
+    const uint32_t roff = dpp32<0x150 + J>(xr), coff = dpp32<0x150 + J>(xc);
+    const Ops<double> o = xo.template bcast<J>();
+    double m = lds_load<double>(tc0 + roff);
+    if (NC > 1) { const double v = lds_load<double>(tc1 + roff); m = v > m ? v : m; }
+    if (NC > 2) { const double v = lds_load<double>(tc2 + roff); m = v > m ? v : m; }
+    if (NC > 2) { const double v = lds_load<double>(tc3 + roff); m = v > m ? v : m; }
+    m = row16_allmax(m);
+    const double val = o.value(m, 0.0, alpha, gamma);
+    if (storer) lds_store<double>(tab_me + coff, val);
     __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+// sixteen (FULL) or nb < 16 consecutive transitions
+template <typename QT, int NC, bool FULL>
+__device__ __forceinline__ void replay_block(int nb, uint32_t xr, uint32_t xc, const Ops<QT>& xo, unsigned tab_me, unsigned tc0, unsigned tc1, unsigned tc2,
+                                             unsigned tc3, bool storer, unsigned long long smask, QT alpha_gamma, QT alpha, QT gamma) {
+#define THRL_TUP_STEP(J)                                                                                                         \
+    if (FULL || (J) < opaque(nb)) {      /* (a scalar compare per step, not sixteen hoisted-and-spilled booleans) */             \
+        if constexpr (std::is_same<QT, float>::value) replay_step_f32<J, NC>(xr, xc, xo.c1, tab_me, tc0, tc1, tc2, tc3, alpha_gamma, smask); \
+        else replay_step_f64<J, NC>(xr, xc, xo, tab_me, tc0, tc1, tc2, tc3, storer, alpha, gamma);                              \
+    }
+    THRL_TUP_STEP(0) THRL_TUP_STEP(1) THRL_TUP_STEP(2) THRL_TUP_STEP(3) THRL_TUP_STEP(4) THRL_TUP_STEP(5) THRL_TUP_STEP(6) THRL_TUP_STEP(7)
+    THRL_TUP_STEP(8) THRL_TUP_STEP(9) THRL_TUP_STEP(10) THRL_TUP_STEP(11) THRL_TUP_STEP(12) THRL_TUP_STEP(13) THRL_TUP_STEP(14) THRL_TUP_STEP(15)
+#undef THRL_TUP_STEP
 }
 
 template <typename QT, int N, int NSEG, bool NOISE, bool SWEEP>
@@ -218,7 +336,6 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     const int A_me = pme.n_actions;
     const unsigned a_bytes = (unsigned)A_me * (unsigned)sizeof(QT);
     const unsigned tab_me = lds_addr(tabs + a.tab_off[ag_ok ? my_ag : 0]);
-    const unsigned hist_me = tab_me;              // (unused: visits are counted from the log)
     const unsigned col_b0 = (unsigned)min(l16, A_me - 1) * (unsigned)sizeof(QT), col_b1 = (unsigned)min(l16 + 16, A_me - 1) * (unsigned)sizeof(QT);
     const unsigned col_b2 = (unsigned)min(l16 + 32, A_me - 1) * (unsigned)sizeof(QT), col_b3 = (unsigned)min(l16 + 48, A_me - 1) * (unsigned)sizeof(QT);
     int amax = 1;
@@ -226,6 +343,8 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     for (int i = 0; i < N; i++) amax = max(amax, a.ag[i].n_actions);
     const int ncol = (amax + 15) >> 4;
     const bool storer = ag_ok && l16 == 0;
+    const unsigned long long smask = __ballot(storer);            // the lanes that store a transition's TD value: lane 16 i, i < N
+    const unsigned tc0 = tab_me + col_b0, tc1 = tab_me + col_b1, tc2 = tab_me + col_b2, tc3 = tab_me + col_b3;
     const TdCoef tc_me = td_coef(pme);
     const QT alpha_me = std::is_same<QT, float>::value ? (QT)tc_me.alpha_f : (QT)tc_me.alpha;
     const QT gamma_me = (QT)pme.gamma;
@@ -307,6 +426,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             // ---- (a) greedy action of every local row (first max wins, numpy.argmax: agents.py:85), lane = row
 #pragma unroll
             for (int i = 0; i < N; i++) {
+                if (kTupAblate & 16) break;
                 const int A = a.ag[i].n_actions, R = a.win_rows[i] + 2;
                 const QT* t = tabs + a.tab_off[i];
                 for (int base = 0; base < R; base += 64) {
@@ -329,7 +449,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             // ---- (b) G[tau] = the agents' greedy actions in state tau, one per byte (entry `tuples`: the initial state)
-            for (int base = 0; base <= tuples; base += 256) {         // four batches of 64 tuples in flight
+            for (int base = 0; base <= tuples && !(kTupAblate & 4); base += 256) {         // four batches of 64 tuples in flight
                 uint32_t pw[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -357,6 +477,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 for (int i = 0; i < N; i++) {
                     const AgentParams& p = a.ag[i];
                     double u; uint32_t ch;
+                    if (kTupAblate & 8) { u = 1.0; ch = 0u; } else
                     if (a.inj_u) {           // parity mode: the reference's recorded draws [E][T][N][G] (agents.py:81-82)
                         const size_t k = (((size_t)e * T + tt) * N + i) * (size_t)a.G + (size_t)g;
                         u = a.inj_u[k]; ch = min((uint32_t)(uint8_t)a.inj_choice[k], (uint32_t)(p.n_actions - 1));
@@ -399,7 +520,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 seq[seg] = 0u; acts[seg] = 0u;
-                const int n = min(64, T - seg * 64);
+                const int n = (kTupAblate & 2) ? 0 : min(64, T - seg * 64);
                 for (int tl = 0; tl < n; tl++) {
                     uint32_t w;
                     if (NOISE && off) {
@@ -443,7 +564,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             const int tau_end = tau;
 
             // ---- (e) lane-parallel over the steps: actions, rows, prices, rewards, old-value snapshot (agents.py:67), logs
-            uint32_t word[NSEG][N];           // ns | cell << 8 (| valid << 31)
+            uint32_t wr[NSEG][N], wc[NSEG][N];           // byte offsets inside the agent's table: next-state row, rewritten cell
             Ops<QT> ops[NSEG][N];
             double lr[N], la[N];
 #pragma unroll
@@ -503,11 +624,12 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                     const double re = __dmul_rn(price, aq);                       // environments.py:33
                     const QT ov = tabs[a.tab_off[i] + cell];
                     ops[seg][i].set(ov, re, SWEEP ? tcs[i] : td_coef(p));
-                    word[seg][i] = ns | (cell << 8);
+                    wr[seg][i] = ns * (uint32_t)A * (uint32_t)sizeof(QT);
+                    wc[seg][i] = cell * (uint32_t)sizeof(QT);
                     if (valid) { lr[i] += re; la[i] += lut_sct[i * 64 + act]; }
                     vw |= (VW)cell << (16 * i);            // visit counter of the transition (agents.py:76): logged, counted after the launch's last episode
                 }
-                if (valid && a.counter) vlog[e * T + tt] = vw;
+                if (valid && a.counter && !(kTupAblate & 32)) vlog[e * T + tt] = vw;
             }
             __builtin_amdgcn_wave_barrier();
 
@@ -518,26 +640,35 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 for (int b = 0; b < 4; b++) {
                     const int base_t = seg * 64 + b * 16;
                     if (base_t >= T) break;
+                    if (kTupAblate & 1) {          // keep the operands alive
+#pragma unroll
+                        for (int i = 0; i < N; i++) asm volatile("" :: "v"(wr[seg][i]), "v"(wc[seg][i]), "v"(*reinterpret_cast<const uint32_t*>(&ops[seg][i])));
+                        break;
+                    }
                     const unsigned sel = (unsigned)(b * 16 + l16) << 2;
-                    uint32_t xw = 0u;
+                    uint32_t xr = 0u, xc = 0u;
                     Ops<QT> xo = ops[seg][0];
 #pragma unroll
                     for (int i = 0; i < N; i++) {
-                        const uint32_t v = bperm(sel, word[seg][i]);
-                        if (my_ag == i) xw = v;
+                        const uint32_t vr = bperm(sel, wr[seg][i]), vc = bperm(sel, wc[seg][i]);
+                        if (my_ag == i) { xr = vr; xc = vc; }
                         xo.gather(sel, ops[seg][i], my_ag == i);
                     }
                     const int nb = min(16, T - base_t);
-                    const bool cnt = false;                   // (counted lane-parallel in phase (e))
-#define THRL_TUP_STEP(J) if ((J) < nb) replay_step<QT, J>(xw, xo, tab_me, hist_me, a_bytes, col_b0, col_b1, col_b2, col_b3, ncol, storer, cnt, SWEEP ? ag_g : ag_me, SWEEP ? alpha_g : alpha_me, SWEEP ? gamma_g : gamma_me);
-                    THRL_TUP_STEP(0) THRL_TUP_STEP(1) THRL_TUP_STEP(2) THRL_TUP_STEP(3) THRL_TUP_STEP(4) THRL_TUP_STEP(5) THRL_TUP_STEP(6) THRL_TUP_STEP(7)
-                    THRL_TUP_STEP(8) THRL_TUP_STEP(9) THRL_TUP_STEP(10) THRL_TUP_STEP(11) THRL_TUP_STEP(12) THRL_TUP_STEP(13) THRL_TUP_STEP(14) THRL_TUP_STEP(15)
-#undef THRL_TUP_STEP
+                    const QT agx = SWEEP ? ag_g : ag_me, alx = SWEEP ? alpha_g : alpha_me, gax = SWEEP ? gamma_g : gamma_me;
+#define THRL_TUP_BLOCK(NC)                                                                                                      \
+                    if (nb == 16) replay_block<QT, NC, true>(nb, xr, xc, xo, tab_me, tc0, tc1, tc2, tc3, storer, smask, agx, alx, gax); \
+                    else replay_block<QT, NC, false>(nb, xr, xc, xo, tab_me, tc0, tc1, tc2, tc3, storer, smask, agx, alx, gax);
+                    if (ncol == 1) { THRL_TUP_BLOCK(1) } else if (ncol == 2) { THRL_TUP_BLOCK(2) } else { THRL_TUP_BLOCK(4) }
+#undef THRL_TUP_BLOCK
                 }
             }
 
             // ---- (g) log sums of this game and episode into the wave accumulators (mean over games: host / finalize)
-            {
+            if (kTupAblate & 64) {
+#pragma unroll
+                for (int i = 0; i < N; i++) asm volatile("" :: "v"(lr[i]), "v"(la[i]));
+            } else {
                 // lane L of tr: reward total of agent L & 3; of ta: action total (already divided by T per step)
                 const double tr = __ddiv_rn(wave_sum4(lr[0], N > 1 ? lr[N > 1 ? 1 : 0] : 0.0, N > 2 ? lr[N > 2 ? 2 : 0] : 0.0,
                                                       N > 3 ? lr[N > 3 ? 3 : 0] : 0.0, lane), (double)T);
@@ -582,7 +713,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         // ---- visit counters (agents.py:76).  The tables are back in HBM, so their LDS region is free: fold the launch's visit
         //      log into a u16 histogram there (E*T <= 32*256 < 65536: no carry) and apply it with plain coalesced read-add-write
         //      (a game's counters belong to this wave alone: no global atomics)
-        if (a.counter) {
+        if (a.counter && !(kTupAblate & 32)) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             for (int k = lane; k < a.hist_dwords; k += 64) hist[k] = 0u;
             __builtin_amdgcn_wave_barrier();
