@@ -324,8 +324,10 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     if ((size_t)hd * 4 > (size_t)elems * esz) NO("visit histogram does not fit the table region");      // (never: u16 per cell)
     a.game_lds_bytes = (int)align_up((size_t)a.g_off + 2 * ((size_t)tuples + 1), 16);
     // action words: agent i's action in a bit field of ceil(log2 A_i) bits; the widths sum to < log2(tuples) + N <= 16
-    int sh = 0;
-    for (int i = 0; i < N; i++) {
+    // (the fields start at bit 1 and the LAST agent's comes first: its field, masked, is its action x 2 = the byte offset of
+    // its term in a u16 table indexed by the tuple -- the play chain of thrl_tuple_kernel.h adds it without a multiply)
+    int sh = 1;
+    for (int i = N - 1; i >= 0; i--) {
         int bits = 0;
         while ((1 << bits) < c->n_actions[i]) bits++;
         a.act_sh[i] = sh; a.act_bits[i] = bits; sh += bits;

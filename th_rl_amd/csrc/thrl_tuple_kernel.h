@@ -281,6 +281,14 @@ __device__ __forceinline__ void replay_step_f64(uint32_t xr, uint32_t xc, const 
 }
 
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+// scalar bit-field extract with a prepared operand (offset | width << 16): one s_bfe_u32 (hipcc emits a shift and an AND)
+__device__ __forceinline__ uint32_t sbfe(uint32_t x, uint32_t op) { uint32_t r; asm("s_bfe_u32 %0, %1, %2" : "=s"(r) : "s"(x), "s"(op) : "scc"); return r; }
+// the u16 at a wave-uniform LDS address, as a scalar (ds_read_u16 zero-extends: no masking afterwards)
+__device__ __forceinline__ uint32_t lds_u16_uniform(uint32_t addr) {
+    uint32_t v, r;
+    asm volatile("ds_read_u16 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %1, %0" : "=&v"(v), "=s"(r) : "v"(addr) : "memory");
+    return r;
+}
 // sixteen (FULL) or nb < 16 consecutive transitions
 template <typename QT, int NC, bool FULL>
 __device__ __forceinline__ void replay_block(int nb, uint32_t xr, uint32_t xc, const Ops<QT>& xo, unsigned tab_me, unsigned tc0, unsigned tc1, unsigned tc2,
@@ -327,6 +335,15 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
     uint32_t fm[N], fmask[N];
 #pragma unroll
     for (int i = 0; i < N; i++) { sh[i] = a.act_sh[i]; fm[i] = (1u << a.act_bits[i]) - 1u; fmask[i] = fm[i] << sh[i]; }
+    // the chain carries the LDS byte address of G[tau]: gbase + 2 tau = gbase + sum_i a_i * gstr[i] (gstr = 2 x the mixed-radix
+    // weight).  The last agent's weight is 1 and its field sits at bit 1, so its term is the masked word itself.
+    const uint32_t gbase = lds_addr(gt);
+    uint32_t gstr[N], bfeop[N];
+    {
+        uint32_t wgt = 2u;
+#pragma unroll
+        for (int i = N - 1; i >= 0; i--) { gstr[i] = wgt; wgt *= (uint32_t)a.ag[i].n_actions; bfeop[i] = (uint32_t)sh[i] | ((uint32_t)a.act_bits[i] << 16); }
+    }
 #define THRL_FLD(x, i) (((uint32_t)(x) >> sh[i]) & fm[i])
 
     // replay ("exec") layout: agent my_ag owns the 16-lane row `lane >> 4`
@@ -410,6 +427,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         __builtin_amdgcn_wave_barrier();
 
         int tau = tuples;                    // current state: action tuple of the last step; `tuples` = the launch's initial state
+        uint32_t ga = gbase + 2u * (uint32_t)tuples;          // ... carried as the address of G[tau]
         // NOISE: a step whose intercept was redrawn (environments.py:29-31) leaves the action grid -- the state after it is
         // "off": its rows are carried explicitly (byte i = agent i's window-local play / train row) instead of a tuple.
         // The launch's initial state is handled the same way.
@@ -419,7 +437,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
         uint32_t init_pw = 0u, init_tw = 0u;          // the initial state's rows, packed as prow / trow are
 #pragma unroll
         for (int i = 0; i < N; i++) { init_pw |= (uint32_t)init_play[i] << (8 * i); init_tw |= (uint32_t)init_train[i] << (8 * i); }
-        if (NOISE) { tau = 0; offp = init_pw; offt = init_tw; }
+        if (NOISE) { tau = 0; ga = gbase; offp = init_pw; offt = init_tw; }
         for (int e = 0; e < a.n_episodes; e++) {
             const uint32_t eg = (uint32_t)(a.first_episode + (uint64_t)e);
 
@@ -517,10 +535,16 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
             // (NOISE: the packed train rows where that state is off the grid; acts[seg] lane t = the actions of step t)
             uint32_t seq[NSEG], acts[NSEG];
             const bool off0 = off;
+            // is the state step (seg, lane) is played in off the grid (NOISE: the step before it redrew the intercept)?
+            auto state_off = [&](int seg) -> bool {
+                if (!NOISE) return false;
+                return lane > 0 ? (bool)((nzm[seg] >> (lane - 1)) & 1ull) : (seg > 0 ? (bool)((nzm[seg > 0 ? seg - 1 : 0] >> 63) & 1ull) : off0);
+            };
 #pragma unroll
             for (int seg = 0; seg < NSEG; seg++) {
                 seq[seg] = 0u; acts[seg] = 0u;
                 const int n = (kTupAblate & 2) ? 0 : min(64, T - seg * 64);
+                const uint32_t CM = Cw[seg] & Mw[seg], NM = ~Mw[seg] & 0xFFFFu;         // per step: the explorers' choices; the greedy agents' fields
                 for (int tl = 0; tl < n; tl++) {
                     uint32_t w;
                     if (NOISE && off) {
@@ -529,23 +553,25 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         for (int i = 0; i < N; i++) wv |= (uint32_t)am[a.am_off_i[i] + (int)((offp >> (8 * i)) & 0xFFu)] << sh[i];
                         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
                     } else {
-                        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)gt[tau]);
+                        w = lds_u16_uniform(ga);
                     }
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)Mw[seg], tl), c = (uint32_t)__builtin_amdgcn_readlane((int)Cw[seg], tl);
-                    const uint32_t ap = (c & m) | (w & ~m);
-                    const uint32_t rec = (NOISE && off) ? offt : (uint32_t)tau;
+                    const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)CM, tl), nm = (uint32_t)__builtin_amdgcn_readlane((int)NM, tl);
+                    const uint32_t ap = (w & nm) | cm;
+                    const uint32_t rec = (NOISE && off) ? offt : ga;         // (addresses become tuples below, lane-parallel)
                     asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(seq[seg]) : "s"(rec), "s"(tl));
                     if (NOISE) asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(acts[seg]) : "s"(ap), "s"(tl));
-                    int nt = 0;
-#pragma unroll
-                    for (int i = 0; i < N; i++) nt = nt * a.ag[i].n_actions + (int)THRL_FLD(ap, i);
-                    tau = nt;
+                    // address of G[tau'], tau' = mixed radix of the actions: the products are independent, the sums a tree
+                    uint32_t t0 = gbase + (ap & fmask[N - 1]), t1 = 0u;
+                    if (N >= 2) t1 = sbfe(ap, bfeop[N >= 2 ? N - 2 : 0]) * gstr[N >= 2 ? N - 2 : 0];
+                    if (N >= 3) t0 += sbfe(ap, bfeop[N >= 3 ? N - 3 : 0]) * gstr[N >= 3 ? N - 3 : 0];
+                    if (N >= 4) t1 += sbfe(ap, bfeop[0]) * gstr[0];
+                    ga = t0 + t1;
                     if (NOISE) {
                         off = (nzm[seg] >> tl) & 1ull;
                         if (off) {           // environments.py:29-33 with the redrawn intercept; rows by both encodes
                             const double na = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(NA[seg]), tl),
                                                                __builtin_amdgcn_readlane(__double2loint(NA[seg]), tl));
-                            double pr = __dsub_rn(na, __dmul_rn(a.env.b, qsum_lut[tau]));
+                            double pr = __dsub_rn(na, __dmul_rn(a.env.b, qsum_lut[(ga - gbase) >> 1]));
                             if (!(pr > 0.0)) pr = 0.0;
                             uint32_t op = 0u, ot = 0u;
 #pragma unroll
@@ -560,7 +586,10 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                         }
                     }
                 }
+                if (!state_off(seg)) seq[seg] = (seq[seg] - gbase) >> 1;           // on-grid states: address of G[tau] -> tau
+                if (kTupAblate & 2) seq[seg] = 0u;                                  // (chain skipped: keep the indices in range)
             }
+            tau = (int)((ga - gbase) >> 1);
             const int tau_end = tau;
 
             // ---- (e) lane-parallel over the steps: actions, rows, prices, rewards, old-value snapshot (agents.py:67), logs
@@ -582,7 +611,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 bool s_off = false, n_off = false;
                 if (NOISE) {
                     n_off = valid && ((nzm[seg] >> lane) & 1ull);
-                    s_off = lane > 0 ? (bool)((nzm[seg] >> (lane - 1)) & 1ull) : (seg > 0 ? (bool)((nzm[seg > 0 ? seg - 1 : 0] >> 63) & 1ull) : off0);
+                    s_off = state_off(seg);
                     if (!valid) { s_off = false; tq = 0u; n_off = false; nxt = 0u; }
                 }
                 uint32_t ap;
