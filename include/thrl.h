@@ -162,7 +162,8 @@ size_t thrl_table_stride(const thrl_cfg* cfg);
 size_t thrl_table_offset(const thrl_cfg* cfg, int agent);
 size_t thrl_replay_mem_bytes(const thrl_cfg* cfg);
 /* scratch the episode kernels need for THIS config on the current device (payoff LUT image, per-wave
- * log partials and transition log of the wave kernel's persistent grid); 0 on a bad config */
+ * log partials and transition log of the wave kernel's persistent grid; LUT image and per-wave visit log
+ * of the tuple-chain kernel's); 0 on a bad config */
 size_t thrl_workspace_bytes(const thrl_cfg* cfg);
 /* which kernel THRL_KERNEL_AUTO would pick for this config (thrl_kernel) */
 int    thrl_select_kernel(const thrl_cfg* cfg, int injected);

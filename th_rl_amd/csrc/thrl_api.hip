@@ -358,9 +358,6 @@ TuplePlan plan_tuple(const thrl_cfg* c, const thrl_run* run) {
     if (best_w == 0) NO("tables of one game do not fit LDS");
     p.waves_per_block = best_w; p.blocks_per_cu = best_b;
     p.ok = true;
-    if (getenv("THRL_DEBUG_PLAN"))
-        fprintf(stderr, "plan_tuple: lut_lds %d game_lds %d (tables %d) waves/block %d blocks/cu %d\n", a.lut_lds_bytes, a.game_lds_bytes,
-                a.am_off, best_w, best_b);
     return p;
 #undef NO
 }
