@@ -465,7 +465,9 @@ def test_kernel_selection_covers_individual_grids_on_the_host(lib):
     # tables and G is u16, which leaves 14 waves per CU (it was 8 with both beside the tables)
     waves, rest = divmod(ws - 160 * 1024, 32 * 25 * 8)
     assert k == "tuple" and rest == 0 and waves == 14 * 256
-    assert sel([a11, dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                 # two agents, different grids
+    k2, ws2 = sel([a11, dict(a21, min_memory=25)], max_steps=25)                            # two agents, different grids
+    waves2, rest2 = divmod(ws2 - 160 * 1024, 32 * 25 * 4)                                   # (their visit-log words are 4 bytes)
+    assert k2 == "tuple" and rest2 == 0 and waves2 == 16 * 256                              # (the kernel's 4 waves per SIMD)
     assert sel([dict(a21, min_memory=25)], max_steps=25)[0] == "tuple"                     # one agent
     assert sel([a11, dict(a21, min_memory=25), a5], max_steps=25, noise_prob=0.05)[0] == "tuple"
     assert sel([a11, dict(a21, min_memory=25), a5], max_steps=10)[0] == "generic"           # buffers fill every 3rd episode
