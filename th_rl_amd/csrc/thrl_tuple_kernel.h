@@ -15,19 +15,23 @@
 //     per-action quantities (a/b)*scale_i(k) and scale_i(k)/T; the price per tuple stays in HBM (L2), it is only
 //     gathered lane-parallel;
 //   * per game and episode: the greedy action of every table row (lane = row; tables are frozen during play), composed
-//     into G[tau] = the agents' greedy actions in state tau, packed one per byte;
-//   * play = a chain of T steps on the SCALAR unit: a = explore ? choice : G[tau] per byte, tau' = mixed radix of a --
-//     one LDS read, two v_readlane, one v_writelane and ~3N scalar instructions per step;
+//     into G[tau] = the agents' greedy actions in state tau as one u16 action word (bit fields, below);
+//   * play = a chain of T steps on the SCALAR unit that carries the LDS address of G[tau]: word = (G[tau] & the greedy
+//     agents' fields) | the explorers' choices (both masks lane-precomputed per step), next address = gbase + sum_i a_i * 2 w_i
+//     (one s_bfe_u32 + s_mul_i32 per agent, the sums as a tree; the last agent's term is its masked field) --
+//     one LDS read, two v_readlane, one v_writelane and ~10 scalar instructions per step;
 //   * everything else is lane-parallel over the steps (lane = step): Philox draws, rows, prices, rewards, the
 //     old-value snapshot (agents.py:67), the log sums;
 //   * replay = train_net's serial loop (agents.py:68-76) for ALL agents at once: agent i owns lanes 16i..16i+15, a
 //     lane reads ceil(A_i/16) columns of the next-state row, four DPP steps give the row maximum, lane 16i stores
 //     the TD value; step operands reach the 16-lane rows by ds_bpermute per 16 steps and row_newbcast DPP per step.
-//     Strictly one transition at a time per agent, in order: no hazard analysis needed.
+//     Strictly one transition at a time per agent, in order: no hazard analysis needed.  The float32 step is hand-written
+//     (replay_step_f32: 11-15 vector instructions, no branch).
 //   * visit counters: every step's cells (u16 per agent) go to a per-wave log in HBM / L2 (coalesced, lane = step); after a
 //     game's tables are written back the log is folded into a u16 histogram that OVERLAYS the table region and is applied
 //     to the int32 counters once per launch (as the wave kernel does: no LDS is spent on the histogram).
-//   * action words: the agents' actions as bit fields (ceil(log2 A_i) bits each, < 16 bits in all), so G is u16.
+//   * action words: the agents' actions as bit fields (ceil(log2 A_i) bits each, laid out from bit 1 with the LAST agent
+//     first, 16 bits in all at most: TupleArgs.act_sh / act_bits), so G is u16.
 //   * env noise (template NOISE, noise_prob > 0): a step whose intercept was redrawn (environments.py:29-31) leaves the
 //     action grid.  The state after it is carried as explicit rows (both encodes of its price, computed once on the
 //     chain from qsum[tau] = the tuple's total quantity); the step played in it reads the agents' greedy actions from
@@ -466,7 +470,7 @@ __global__ void __launch_bounds__(1024) k_tuple_episodes(const TupleArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- (b) G[tau] = the agents' greedy actions in state tau, one per byte (entry `tuples`: the initial state)
+            // ---- (b) G[tau] = the agents' greedy actions in state tau, one action word (entry `tuples`: the initial state)
             for (int base = 0; base <= tuples && !(kTupAblate & 4); base += 256) {         // four batches of 64 tuples in flight
                 uint32_t pw[4];
 #pragma unroll
